@@ -1,0 +1,811 @@
+// az_engine.hip -- host side of libazamd.so: the C ABI of include/azamd.h, engine handles, device arenas.
+//
+// Reference interfaces replaced (see include/azamd.h for the per-function citations):
+//   MCTS / MCTS_AZ object life cycle and get_action_visits   MCTS.py:90-171
+//   AlphaZeroPlayer.get_action                                player.py:101-116
+//   Game.start_self_play / Pipeline.data_collector            game.py:35-58, Pipeline.py:53-63
+// There is no CPU path in this file: every compute entry point launches gfx950 kernels or fails.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "az_cnn.hpp"
+#include "az_internal.hpp"
+#include "az_play.hpp"
+
+namespace az {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+struct GameInfo {
+    int A, W, LG, MAXD, MAX_PLIES;
+};
+static bool game_info(int game, GameInfo& gi) {
+    switch (game) {
+        case AZ_GAME_C4: gi = {C4::A, C4::W, C4::LG, C4::MAXD, C4::MAX_PLIES}; return true;
+        case AZ_GAME_TTT: gi = {TTT::A, TTT::W, TTT::LG, TTT::MAXD, TTT::MAX_PLIES}; return true;
+        case AZ_GAME_NBTTT: gi = {NBTTT::A, NBTTT::W, NBTTT::LG, NBTTT::MAXD, NBTTT::MAX_PLIES}; return true;
+    }
+    return false;
+}
+
+static int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device: libazamd has no CPU path");
+        return AZ_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device ordinal out of range");
+        return AZ_ERR_ARG;
+    }
+    AZ_HIP(hipSetDevice(device));
+    return AZ_OK;
+}
+
+// {f32(c_init + ln((1+Np+c_base)/c_base)), f32(sqrt(Np))}: float64 on the host (glibc), rounded once (MCTS.py:53-54).
+static void build_puct_table(double c_init, int c_base, int n, std::vector<float2>& out) {
+    out.resize(n);
+    for (int np = 0; np < n; np++) {
+        double A = c_init + log((double)(1 + np + c_base) / (double)c_base);
+        out[np] = make_float2((float)A, (float)sqrt((double)np));
+    }
+}
+
+
+struct TmpBufs {
+    std::vector<void*> v;
+    ~TmpBufs() {
+        for (void* p : v) (void)hipFree(p);
+    }
+    template <class T>
+    int get(T** p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            return AZ_ERR_HIP;
+        }
+        v.push_back(q);
+        *p = (T*)q;
+        return AZ_OK;
+    }
+};
+
+}  // namespace az
+
+using namespace az;
+
+struct az_engine {
+    az_config cfg;
+    GameInfo gi;
+    Dev d;
+    Play p;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    u8* flip_bits = nullptr;
+    i32* d_actions = nullptr;
+    float* d_pi = nullptr;
+    double* d_temps = nullptr;
+    i32 *rc_actions = nullptr, *rc_visits = nullptr, *rc_n = nullptr, *rc_rootN = nullptr;
+    float *rc_q = nullptr, *rc_p = nullptr, *rc_rootQ = nullptr;
+    u8* d_flags8 = nullptr;
+    Cnn* net = nullptr;
+    unsigned long long target = 0;
+    int recording = 0;
+
+    template <class T>
+    int dalloc(T** p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            return AZ_ERR_HIP;
+        }
+        allocs.push_back(q);
+        *p = (T*)q;
+        return AZ_OK;
+    }
+};
+
+#define AZ_TRY(x)                 \
+    do {                          \
+        int _r = (x);             \
+        if (_r != AZ_OK) return _r; \
+    } while (0)
+#define AZ_CHECK_E(e)                    \
+    if (!(e)) {                          \
+        set_error("null engine handle"); \
+        return AZ_ERR_ARG;               \
+    }                                    \
+    AZ_HIP(hipSetDevice((e)->cfg.device))
+
+extern "C" {
+
+const char* az_last_error(void) { return g_err.c_str(); }
+int az_version(void) { return 100; }
+int az_state_words(int game) {
+    GameInfo gi;
+    return game_info(game, gi) ? gi.W : -1;
+}
+int az_n_actions(int game) {
+    GameInfo gi;
+    return game_info(game, gi) ? gi.A : -1;
+}
+int az_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ K1 host wrappers
+int az_env_step_batch(int game, int device, int64_t n, const uint64_t* states_in, const int32_t* actions,
+                      uint64_t* states_out, uint8_t* placed, int8_t* winner, uint8_t* done, uint16_t* legal) {
+    GameInfo gi;
+    if (!game_info(game, gi) || n < 0 || !states_in) {
+        set_error("az_env_step_batch: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(device));
+    if (n == 0) return AZ_OK;
+    TmpBufs t;
+    u64 *din, *dout;
+    i32* dact = nullptr;
+    u8 *dpl, *ddn;
+    i8* dwn;
+    u16* dlg;
+    AZ_TRY(t.get(&din, n * gi.W));
+    AZ_TRY(t.get(&dout, n * gi.W));
+    AZ_TRY(t.get(&dpl, n));
+    AZ_TRY(t.get(&ddn, n));
+    AZ_TRY(t.get(&dwn, n));
+    AZ_TRY(t.get(&dlg, n));
+    AZ_HIP(hipMemcpy(din, states_in, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
+    if (actions) {
+        AZ_TRY(t.get(&dact, n));
+        AZ_HIP(hipMemcpy(dact, actions, n * sizeof(i32), hipMemcpyHostToDevice));
+    }
+    AZ_TRY(launch_env_step(game, n, din, dact, dout, dpl, dwn, ddn, dlg, 0));
+    AZ_HIP(hipDeviceSynchronize());
+    if (states_out) AZ_HIP(hipMemcpy(states_out, dout, n * gi.W * sizeof(u64), hipMemcpyDeviceToHost));
+    if (placed) AZ_HIP(hipMemcpy(placed, dpl, n, hipMemcpyDeviceToHost));
+    if (winner) AZ_HIP(hipMemcpy(winner, dwn, n, hipMemcpyDeviceToHost));
+    if (done) AZ_HIP(hipMemcpy(done, ddn, n, hipMemcpyDeviceToHost));
+    if (legal) AZ_HIP(hipMemcpy(legal, dlg, n * sizeof(u16), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_env_status_batch(int game, int device, int64_t n, const uint64_t* states, int8_t* winner, uint8_t* done,
+                        uint16_t* legal, uint8_t* full) {
+    GameInfo gi;
+    if (!game_info(game, gi) || n < 0 || !states) {
+        set_error("az_env_status_batch: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(device));
+    if (n == 0) return AZ_OK;
+    TmpBufs t;
+    u64* din;
+    u8 *ddn, *dfl;
+    i8* dwn;
+    u16* dlg;
+    AZ_TRY(t.get(&din, n * gi.W));
+    AZ_TRY(t.get(&ddn, n));
+    AZ_TRY(t.get(&dfl, n));
+    AZ_TRY(t.get(&dwn, n));
+    AZ_TRY(t.get(&dlg, n));
+    AZ_HIP(hipMemcpy(din, states, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
+    AZ_TRY(launch_env_status(game, n, din, dwn, ddn, dlg, dfl, 0));
+    AZ_HIP(hipDeviceSynchronize());
+    if (winner) AZ_HIP(hipMemcpy(winner, dwn, n, hipMemcpyDeviceToHost));
+    if (done) AZ_HIP(hipMemcpy(done, ddn, n, hipMemcpyDeviceToHost));
+    if (legal) AZ_HIP(hipMemcpy(legal, dlg, n * sizeof(u16), hipMemcpyDeviceToHost));
+    if (full) AZ_HIP(hipMemcpy(full, dfl, n, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_env_planes_batch(int game, int device, int64_t n, const uint64_t* states, float* planes) {
+    GameInfo gi;
+    if (!game_info(game, gi) || n < 0 || !states || !planes) {
+        set_error("az_env_planes_batch: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(device));
+    if (n == 0) return AZ_OK;
+    size_t per = game == AZ_GAME_C4 ? 126 : (game == AZ_GAME_TTT ? 27 : 252);
+    TmpBufs t;
+    u64* din;
+    float* dpl;
+    AZ_TRY(t.get(&din, n * gi.W));
+    AZ_TRY(t.get(&dpl, n * per));
+    AZ_HIP(hipMemcpy(din, states, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
+    AZ_TRY(launch_env_planes(game, n, din, dpl, 0));
+    AZ_HIP(hipDeviceSynchronize());
+    AZ_HIP(hipMemcpy(planes, dpl, n * per * sizeof(float), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_env_flip_batch(int game, int device, int64_t n, const uint64_t* states, uint64_t* flipped, int8_t* flip_action) {
+    GameInfo gi;
+    if (!game_info(game, gi) || n < 0 || !states) {
+        set_error("az_env_flip_batch: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(device));
+    if (n == 0) return AZ_OK;
+    TmpBufs t;
+    u64 *din, *dout;
+    i8* dfa;
+    AZ_TRY(t.get(&din, n * gi.W));
+    AZ_TRY(t.get(&dout, n * gi.W));
+    AZ_TRY(t.get(&dfa, n * gi.A));
+    AZ_HIP(hipMemcpy(din, states, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
+    AZ_TRY(launch_env_flip(game, n, din, dout, dfa, 0));
+    AZ_HIP(hipDeviceSynchronize());
+    if (flipped) AZ_HIP(hipMemcpy(flipped, dout, n * gi.W * sizeof(u64), hipMemcpyDeviceToHost));
+    if (flip_action) AZ_HIP(hipMemcpy(flip_action, dfa, n * gi.A, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_env_step_batch_dev(int game, int64_t n, const uint64_t* states_in_dev, const int32_t* actions_dev,
+                          uint64_t* states_out_dev, uint8_t* placed_dev, int8_t* winner_dev, uint8_t* done_dev,
+                          uint16_t* legal_dev) {
+    return launch_env_step(game, n, states_in_dev, actions_dev, states_out_dev, placed_dev, winner_dev, done_dev,
+                           legal_dev, 0);
+}
+
+int az_puct_batch(int device, double c_init, int32_t c_base, int64_t n, const int32_t* Np, const int32_t* nv,
+                  const float* Q, const float* P, float* score) {
+    if (n < 0 || !Np || !nv || !Q || !P || !score) {
+        set_error("az_puct_batch: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(device));
+    if (n == 0) return AZ_OK;
+    int maxnp = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (Np[i] > maxnp) maxnp = Np[i];
+    std::vector<float2> tab;
+    build_puct_table(c_init, c_base, maxnp + 1, tab);
+    TmpBufs t;
+    i32 *dNp, *dnv;
+    float *dQ, *dP, *ds;
+    float2* dtab;
+    AZ_TRY(t.get(&dNp, n));
+    AZ_TRY(t.get(&dnv, n));
+    AZ_TRY(t.get(&dQ, n));
+    AZ_TRY(t.get(&dP, n));
+    AZ_TRY(t.get(&ds, n));
+    AZ_TRY(t.get(&dtab, tab.size()));
+    AZ_HIP(hipMemcpy(dNp, Np, n * 4, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(dnv, nv, n * 4, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(dQ, Q, n * 4, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(dP, P, n * 4, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    AZ_TRY(launch_puct(c_init, c_base, n, dNp, dnv, dQ, dP, dtab, (i32)tab.size(), ds, 0));
+    AZ_HIP(hipDeviceSynchronize());
+    AZ_HIP(hipMemcpy(score, ds, n * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ engine
+int az_engine_create(const az_config* cfg, az_engine** out) {
+    if (!cfg || !out) {
+        set_error("az_engine_create: null argument");
+        return AZ_ERR_ARG;
+    }
+    GameInfo gi;
+    if (!game_info(cfg->game, gi) || cfg->n_games <= 0 || cfg->n_playout <= 0) {
+        set_error("az_engine_create: bad game / n_games / n_playout");
+        return AZ_ERR_ARG;
+    }
+    if (cfg->evaluator == AZ_EVAL_CNN && cfg->game != AZ_GAME_C4) {
+        set_error("AZ_EVAL_CNN exists for Connect4 only (the reference has no usable TTT/NBTTT checkpoint)");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(use_device(cfg->device));
+    az_engine* e = new az_engine();
+    e->cfg = *cfg;
+    e->gi = gi;
+    if (e->cfg.c_base <= 0) e->cfg.c_base = 500;
+    int max_plies = cfg->max_plies > 0 ? cfg->max_plies : gi.MAX_PLIES;
+    if (max_plies > gi.MAX_PLIES) max_plies = gi.MAX_PLIES;
+    i64 cap = cfg->nodes_per_game;
+    if (cap <= 0) cap = 1 + (i64)gi.A * cfg->n_playout * (cfg->reuse_tree ? max_plies : 1);
+    if (cap > (i64)LINK_FIRST_MASK) cap = LINK_FIRST_MASK;
+    const i64 G = cfg->n_games;
+    Dev& d = e->d;
+    memset(&d, 0, sizeof(d));
+    memset(&e->p, 0, sizeof(e->p));
+    d.game = cfg->game;
+    d.G = (i32)G;
+    d.S = cfg->n_playout;
+    d.A = gi.A;
+    d.W = gi.W;
+    d.MAXD = gi.MAXD;
+    d.cap = cap;
+    d.c_init = cfg->c_init;
+    d.c_base = e->cfg.c_base;
+    d.evaluator = cfg->evaluator;
+    d.eval_seed = cfg->eval_seed;
+    d.flip_mode = gi.LG && cfg->game != AZ_GAME_NBTTT ? cfg->flip_mode : AZ_FLIP_NEVER;
+    d.rng_seed = cfg->rng_seed;
+    d.noise_alpha = cfg->dirichlet_alpha > 0 ? (float)cfg->dirichlet_alpha : 0.f;
+    int rc = AZ_OK;
+#define A_(ptr, n) if (rc == AZ_OK) rc = e->dalloc(&(ptr), (size_t)(n))
+    A_(d.nodes, G * cap);
+    A_(d.root_state, G * gi.W);
+    A_(d.root, G);
+    A_(d.n_alloc, G);
+    A_(d.active, G);
+    A_(d.flip_pos, G);
+    A_(d.sim_ctr, G);
+    A_(d.game_id, G);
+    A_(d.path_idx, G * gi.MAXD);
+    A_(d.path_N, G * gi.MAXD);
+    A_(d.path_Q, G * gi.MAXD);
+    A_(d.leaf_depth, G);
+    A_(d.leaf_flags, G);
+    A_(d.leaf_tvalue, G);
+    A_(d.leaf_state, G * gi.W);
+    A_(d.eval_probs, G * gi.A);
+    A_(d.eval_value, G);
+    A_(d.eval_list, G);
+    A_(d.eval_count, 4);
+    A_(d.winner, G);
+    A_(d.done, G);
+    A_(d.ply, G);
+    A_(d.stats, ST_N);
+    A_(d.err, 4);
+    A_(e->d_actions, G);
+    A_(e->d_pi, G * gi.A);
+    A_(e->d_temps, G);
+    A_(e->rc_actions, G * gi.A);
+    A_(e->rc_visits, G * gi.A);
+    A_(e->rc_q, G * gi.A);
+    A_(e->rc_p, G * gi.A);
+    A_(e->rc_n, G);
+    A_(e->rc_rootN, G);
+    A_(e->rc_rootQ, G);
+    A_(e->d_flags8, G);
+    Play& p = e->p;
+    A_(p.tj_state, G * gi.MAX_PLIES * gi.W);
+    A_(p.tj_pi, G * gi.MAX_PLIES * gi.A);
+    A_(p.tj_action, G * gi.MAX_PLIES);
+    A_(p.tj_player, G * gi.MAX_PLIES);
+    p.out_cap = G * gi.MAX_PLIES * 2;
+    A_(p.out_state, p.out_cap * gi.W);
+    A_(p.out_pi, p.out_cap * gi.A);
+    A_(p.out_z, p.out_cap);
+    A_(p.out_player, p.out_cap);
+    A_(p.out_action, p.out_cap);
+    A_(p.out_done, p.out_cap);
+    A_(p.out_gid, p.out_cap);
+    A_(p.out_count, 1);
+    A_(p.out_games, 1);
+    A_(p.games_started, 1);
+    // PUCT table: root visit counts can reach S*(plies+1) with tree reuse.
+    int tab_n = cfg->n_playout * (max_plies + 2) + 64;
+    if (tab_n < 65536) tab_n = 65536;
+    std::vector<float2> tab;
+    build_puct_table(cfg->c_init, e->cfg.c_base, tab_n, tab);
+    float2* dtab = nullptr;
+    A_(dtab, tab_n);
+#undef A_
+    if (rc != AZ_OK) {
+        az_engine_destroy(e);
+        return rc;
+    }
+    d.tab = dtab;
+    d.tab_n = tab_n;
+    hipError_t he = hipStreamCreate(&e->stream);
+    if (he != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        az_engine_destroy(e);
+        return AZ_ERR_HIP;
+    }
+    (void)hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice);
+    (void)hipMemset(d.stats, 0, ST_N * sizeof(unsigned long long));
+    (void)hipMemset(d.err, 0, 16);
+    (void)hipMemset(d.eval_count, 0, 16);
+    (void)hipMemset(p.out_count, 0, 8);
+    (void)hipMemset(p.out_games, 0, 8);
+    (void)hipMemset(p.games_started, 0, 8);
+    (void)hipMemset(d.root_state, 0, G * gi.W * sizeof(u64));
+    *out = e;
+    rc = az_reset_games(e);
+    if (rc != AZ_OK) {
+        az_engine_destroy(e);
+        *out = nullptr;
+        return rc;
+    }
+    return AZ_OK;
+}
+
+void az_engine_destroy(az_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+    }
+    if (e->net) cnn_destroy(e->net);
+    for (void* q : e->allocs) (void)hipFree(q);
+    if (e->flip_bits) (void)hipFree(e->flip_bits);
+    delete e;
+}
+
+int az_engine_sync(az_engine* e) {
+    AZ_CHECK_E(e);
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    u32 err = 0;
+    AZ_HIP(hipMemcpy(&err, e->d.err, sizeof(u32), hipMemcpyDeviceToHost));
+    if (err & 1u) {
+        set_error("node arena overflow: raise az_config.nodes_per_game / max_plies");
+        return AZ_ERR_ARENA;
+    }
+    if (err & 4u) {
+        set_error("trajectory buffer overflow: fetch trajectories more often");
+        return AZ_ERR_ARENA;
+    }
+    return AZ_OK;
+}
+
+int az_get_stats(az_engine* e, az_stats* out) {
+    AZ_CHECK_E(e);
+    if (!out) return AZ_ERR_ARG;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    unsigned long long st[ST_N];
+    AZ_HIP(hipMemcpy(st, e->d.stats, sizeof(st), hipMemcpyDeviceToHost));
+    std::vector<u32> na(e->d.G);
+    AZ_HIP(hipMemcpy(na.data(), e->d.n_alloc, e->d.G * sizeof(u32), hipMemcpyDeviceToHost));
+    i64 used = 0;
+    for (u32 v : na) used += v;
+    out->playouts = (i64)st[ST_PLAYOUTS];
+    out->levels = (i64)st[ST_LEVELS];
+    out->leaf_evals = (i64)st[ST_EVALS];
+    out->terminal_hits = (i64)st[ST_TERMINAL];
+    out->children = (i64)st[ST_CHILDREN];
+    out->nodes_used = used;
+    out->games_finished = (i64)st[ST_GAMES];
+    out->plies = (i64)st[ST_PLIES];
+    return AZ_OK;
+}
+
+int az_reset_stats(az_engine* e) {
+    AZ_CHECK_E(e);
+    AZ_HIP(hipMemsetAsync(e->d.stats, 0, ST_N * sizeof(unsigned long long), e->stream));
+    return AZ_OK;
+}
+
+int az_set_noise(az_engine* e, double alpha) {
+    AZ_CHECK_E(e);
+    e->d.noise_alpha = alpha > 0 ? (float)alpha : 0.f;
+    e->cfg.dirichlet_alpha = alpha;
+    return AZ_OK;
+}
+
+int az_set_n_playout(az_engine* e, int32_t n) {
+    AZ_CHECK_E(e);
+    if (n <= 0) return AZ_ERR_ARG;
+    e->cfg.n_playout = n;
+    e->d.S = n;
+    return AZ_OK;
+}
+
+int az_reset_games(az_engine* e) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    AZ_HIP(hipMemsetAsync(d.root_state, 0, (size_t)d.G * d.W * sizeof(u64), e->stream));
+    AZ_TRY(launch_init_slots(d, e->cfg.game == AZ_GAME_NBTTT ? 1 : 0, e->cfg.game_id_base, e->stream));
+    unsigned long long g = (unsigned long long)d.G;
+    AZ_HIP(hipMemcpyAsync(e->p.games_started, &g, 8, hipMemcpyHostToDevice, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+int az_set_roots(az_engine* e, const uint64_t* states) {
+    AZ_CHECK_E(e);
+    if (!states) return AZ_ERR_ARG;
+    const Dev& d = e->d;
+    AZ_HIP(hipMemcpyAsync(d.root_state, states, (size_t)d.G * d.W * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(launch_init_slots(d, 0, e->cfg.game_id_base, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+int az_get_roots(az_engine* e, uint64_t* states, int8_t* winner, uint8_t* done) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (states) AZ_HIP(hipMemcpy(states, d.root_state, (size_t)d.G * d.W * sizeof(u64), hipMemcpyDeviceToHost));
+    if (winner) AZ_HIP(hipMemcpy(winner, d.winner, d.G, hipMemcpyDeviceToHost));
+    if (done) AZ_HIP(hipMemcpy(done, d.done, d.G, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_set_flip_stream(az_engine* e, const uint8_t* bits, int64_t n_per_game) {
+    AZ_CHECK_E(e);
+    if (!bits || n_per_game <= 0) return AZ_ERR_ARG;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (e->flip_bits) (void)hipFree(e->flip_bits);
+    e->flip_bits = nullptr;
+    size_t bytes = (size_t)e->d.G * n_per_game;
+    AZ_HIP(hipMalloc((void**)&e->flip_bits, bytes));
+    AZ_HIP(hipMemcpy(e->flip_bits, bits, bytes, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemset(e->d.flip_pos, 0, e->d.G * sizeof(u32)));
+    e->d.flip_bits = e->flip_bits;
+    e->d.flip_n = n_per_game;
+    return AZ_OK;
+}
+
+int az_search(az_engine* e, int32_t n_sims) {
+    AZ_CHECK_E(e);
+    if (n_sims <= 0) n_sims = e->cfg.n_playout;
+    const Dev& d = e->d;
+    if (d.flip_mode == AZ_FLIP_STREAM && !d.flip_bits) {
+        set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
+        return AZ_ERR_STATE;
+    }
+    if (d.evaluator == AZ_EVAL_UNIFORM || d.evaluator == AZ_EVAL_HASH) return launch_search_fused(d, n_sims, e->stream);
+    if (d.evaluator == AZ_EVAL_CNN) {
+        if (!e->net) {
+            set_error("AZ_EVAL_CNN: call az_net_load first");
+            return AZ_ERR_NO_NET;
+        }
+        for (int s = 0; s < n_sims; s++) {
+            AZ_TRY(launch_select(d, e->stream));
+            AZ_TRY(cnn_eval_leaves(e->net, d, e->stream));
+            AZ_TRY(launch_backup(d, e->stream));
+        }
+        return AZ_OK;
+    }
+    set_error("az_search: AZ_EVAL_HOST engines are driven with az_select / az_backup");
+    return AZ_ERR_STATE;
+}
+
+int az_select(az_engine* e, uint64_t* leaf_states, uint8_t* flags) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    if (d.flip_mode == AZ_FLIP_STREAM && !d.flip_bits) {
+        set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
+        return AZ_ERR_STATE;
+    }
+    AZ_TRY(launch_select(d, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (leaf_states)
+        AZ_HIP(hipMemcpy(leaf_states, d.leaf_state, (size_t)d.G * d.W * sizeof(u64), hipMemcpyDeviceToHost));
+    if (flags) {
+        std::vector<u32> f(d.G);
+        AZ_HIP(hipMemcpy(f.data(), d.leaf_flags, d.G * sizeof(u32), hipMemcpyDeviceToHost));
+        for (int g = 0; g < d.G; g++)
+            flags[g] = (f[g] & 8u) ? (uint8_t)((f[g] & 1u) | (f[g] & 2u)) : (uint8_t)4u;  // bit2: slot idle
+    }
+    return AZ_OK;
+}
+
+int az_backup(az_engine* e, const float* probs, const float* values) {
+    AZ_CHECK_E(e);
+    if (!probs || !values) return AZ_ERR_ARG;
+    const Dev& d = e->d;
+    AZ_HIP(hipMemcpyAsync(d.eval_probs, probs, (size_t)d.G * d.A * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    AZ_HIP(hipMemcpyAsync(d.eval_value, values, (size_t)d.G * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(launch_backup(d, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+int az_get_root_children(az_engine* e, int32_t* actions, int32_t* visits, float* q, float* prior, int32_t* n_children,
+                         int32_t* root_visits, float* root_q) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    AZ_TRY(launch_root_children(d, e->rc_actions, e->rc_visits, e->rc_q, e->rc_p, e->rc_n, e->rc_rootN, e->rc_rootQ,
+                                e->stream));
+    AZ_TRY(az_engine_sync(e));
+    size_t ga = (size_t)d.G * d.A;
+    if (actions) AZ_HIP(hipMemcpy(actions, e->rc_actions, ga * 4, hipMemcpyDeviceToHost));
+    if (visits) AZ_HIP(hipMemcpy(visits, e->rc_visits, ga * 4, hipMemcpyDeviceToHost));
+    if (q) AZ_HIP(hipMemcpy(q, e->rc_q, ga * 4, hipMemcpyDeviceToHost));
+    if (prior) AZ_HIP(hipMemcpy(prior, e->rc_p, ga * 4, hipMemcpyDeviceToHost));
+    if (n_children) AZ_HIP(hipMemcpy(n_children, e->rc_n, d.G * 4, hipMemcpyDeviceToHost));
+    if (root_visits) AZ_HIP(hipMemcpy(root_visits, e->rc_rootN, d.G * 4, hipMemcpyDeviceToHost));
+    if (root_q) AZ_HIP(hipMemcpy(root_q, e->rc_rootQ, d.G * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_choose_moves(az_engine* e, const double* temps, double temp_all, int32_t* actions, float* pi) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    if (temps) AZ_HIP(hipMemcpyAsync(e->d_temps, temps, d.G * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(launch_choose(d, e->p, temps ? e->d_temps : nullptr, temp_all, -1, e->cfg.move_mode, e->d_actions, e->d_pi,
+                         e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (actions) AZ_HIP(hipMemcpy(actions, e->d_actions, d.G * 4, hipMemcpyDeviceToHost));
+    if (pi) AZ_HIP(hipMemcpy(pi, e->d_pi, (size_t)d.G * d.A * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_advance(az_engine* e, const int32_t* actions) {
+    AZ_CHECK_E(e);
+    if (!actions) return AZ_ERR_ARG;
+    const Dev& d = e->d;
+    AZ_HIP(hipMemcpyAsync(e->d_actions, actions, d.G * 4, hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(launch_advance(d, e->p, e->d_actions, e->d_pi, e->cfg.reuse_tree, 0, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+int az_selfplay_step(az_engine* e, double temp, int32_t first_n_steps, int32_t refill) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    AZ_TRY(az_search(e, e->cfg.n_playout));
+    AZ_TRY(launch_choose(d, e->p, nullptr, temp, first_n_steps, e->cfg.move_mode, e->d_actions, e->d_pi, e->stream));
+    AZ_TRY(launch_advance(d, e->p, e->d_actions, e->d_pi, e->cfg.reuse_tree, 1, e->stream));
+    if (refill) {
+        unsigned long long target = e->target ? e->target : ~0ull;
+        AZ_TRY(launch_refill(d, e->p, target, e->cfg.game_id_base, e->stream));
+    }
+    return AZ_OK;
+}
+
+int az_set_game_target(az_engine* e, int64_t n_games_target) {
+    AZ_CHECK_E(e);
+    e->target = n_games_target > 0 ? (unsigned long long)n_games_target : 0ull;
+    return AZ_OK;
+}
+
+int64_t az_selfplay(az_engine* e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_steps) {
+    AZ_CHECK_E(e);
+    if (n_games_target <= 0) return AZ_ERR_ARG;
+    AZ_TRY(az_reset_games(e));
+    e->target = (unsigned long long)n_games_target;
+    const Dev& d = e->d;
+    if (n_games_target < d.G) {  // fewer games than slots: park the surplus slots
+        std::vector<u8> act(d.G, 0);
+        for (i64 g = 0; g < n_games_target; g++) act[g] = 1;
+        AZ_HIP(hipMemcpy(d.active, act.data(), d.G, hipMemcpyHostToDevice));
+    }
+    unsigned long long zero = 0;
+    AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(e->p.out_games, &zero, 8, hipMemcpyHostToDevice));
+    unsigned long long finished = 0;
+    for (int64_t step = 0; max_steps <= 0 || step < max_steps; step++) {
+        AZ_TRY(az_selfplay_step(e, temp, first_n_steps, 1));
+        int rc = az_engine_sync(e);
+        if (rc != AZ_OK) return rc;
+        AZ_HIP(hipMemcpy(&finished, e->p.out_games, 8, hipMemcpyDeviceToHost));
+        if (finished >= (unsigned long long)n_games_target) break;
+    }
+    return (int64_t)finished;
+}
+
+int az_traj_count(az_engine* e, int64_t* n_games, int64_t* n_plies) {
+    AZ_CHECK_E(e);
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    unsigned long long a = 0, b = 0;
+    AZ_HIP(hipMemcpy(&a, e->p.out_games, 8, hipMemcpyDeviceToHost));
+    AZ_HIP(hipMemcpy(&b, e->p.out_count, 8, hipMemcpyDeviceToHost));
+    if ((i64)b > e->p.out_cap) b = (unsigned long long)e->p.out_cap;
+    if (n_games) *n_games = (int64_t)a;
+    if (n_plies) *n_plies = (int64_t)b;
+    return AZ_OK;
+}
+
+int64_t az_traj_fetch(az_engine* e, int64_t max_plies, uint64_t* states, float* pi, float* z, int8_t* player,
+                      int8_t* action, uint8_t* done, uint64_t* game_id, int clear) {
+    AZ_CHECK_E(e);
+    int64_t ng = 0, np = 0;
+    AZ_TRY(az_traj_count(e, &ng, &np));
+    int64_t n = np < max_plies ? np : max_plies;
+    const Dev& d = e->d;
+    const Play& p = e->p;
+    if (n > 0) {
+        if (states) AZ_HIP(hipMemcpy(states, p.out_state, (size_t)n * d.W * 8, hipMemcpyDeviceToHost));
+        if (pi) AZ_HIP(hipMemcpy(pi, p.out_pi, (size_t)n * d.A * 4, hipMemcpyDeviceToHost));
+        if (z) AZ_HIP(hipMemcpy(z, p.out_z, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (player) AZ_HIP(hipMemcpy(player, p.out_player, (size_t)n, hipMemcpyDeviceToHost));
+        if (action) AZ_HIP(hipMemcpy(action, p.out_action, (size_t)n, hipMemcpyDeviceToHost));
+        if (done) AZ_HIP(hipMemcpy(done, p.out_done, (size_t)n, hipMemcpyDeviceToHost));
+        if (game_id) AZ_HIP(hipMemcpy(game_id, p.out_gid, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    if (clear) {
+        AZ_HIP(hipMemset(p.out_count, 0, 8));
+        AZ_HIP(hipMemset(p.out_games, 0, 8));
+    }
+    return n;
+}
+
+int az_traj_record_bytes(int game) {
+    GameInfo gi;
+    return game_info(game, gi) ? gi.W * 8 + gi.A * 4 + 4 : -1;
+}
+
+int64_t az_traj_pack_dev(az_engine* e, int64_t max_plies, void* out_dev, int clear) {
+    AZ_CHECK_E(e);
+    int64_t ng = 0, np = 0;
+    AZ_TRY(az_traj_count(e, &ng, &np));
+    int64_t n = np < max_plies ? np : max_plies;
+    if (n > 0) {
+        if (!out_dev) return AZ_ERR_ARG;
+        AZ_TRY(launch_traj_pack(e->cfg.game, e->p, n, (u8*)out_dev, e->stream));
+        AZ_HIP(hipStreamSynchronize(e->stream));
+    }
+    if (clear) {
+        AZ_HIP(hipMemset(e->p.out_count, 0, 8));
+        AZ_HIP(hipMemset(e->p.out_games, 0, 8));
+    }
+    return n;
+}
+
+int az_traj_unpack_dev(int game, int64_t n, const void* packed_dev, float* state_dev, float* prob_dev,
+                       float* value_dev, int32_t* winner_dev, float* next_state_dev, uint8_t* done_dev) {
+    GameInfo gi;
+    if (!game_info(game, gi) || n < 0 || (n > 0 && !packed_dev)) {
+        set_error("az_traj_unpack_dev: bad argument");
+        return AZ_ERR_ARG;
+    }
+    AZ_TRY(launch_traj_unpack(game, n, (const u8*)packed_dev, state_dev, prob_dev, value_dev, winner_dev,
+                              next_state_dev, done_dev, 0));
+    AZ_HIP(hipStreamSynchronize(0));
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ network
+int az_net_load(az_engine* e, const float* blob, size_t n_floats) {
+    AZ_CHECK_E(e);
+    if (e->cfg.game != AZ_GAME_C4) {
+        set_error("az_net_load: the CNN is the Connect4 network");
+        return AZ_ERR_ARG;
+    }
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (e->net) {
+        cnn_destroy(e->net);
+        e->net = nullptr;
+    }
+    return cnn_create(blob, n_floats, e->d.G, &e->net);
+}
+
+int az_net_forward(az_engine* e, int64_t n, const uint64_t* states, float* logp, float* logv, float* probs,
+                   float* value) {
+    AZ_CHECK_E(e);
+    if (!e->net) {
+        set_error("az_net_forward: call az_net_load first");
+        return AZ_ERR_NO_NET;
+    }
+    if (n < 0 || !states) return AZ_ERR_ARG;
+    if (n == 0) return AZ_OK;
+    TmpBufs t;
+    u64* ds;
+    float *dlp, *dlv, *dp, *dv;
+    AZ_TRY(t.get(&ds, n * 2));
+    AZ_TRY(t.get(&dlp, n * 7));
+    AZ_TRY(t.get(&dlv, n * 3));
+    AZ_TRY(t.get(&dp, n * 7));
+    AZ_TRY(t.get(&dv, n));
+    AZ_HIP(hipMemcpy(ds, states, n * 16, hipMemcpyHostToDevice));
+    AZ_TRY(cnn_forward(e->net, n, ds, dlp, dlv, dp, dv, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    if (logp) AZ_HIP(hipMemcpy(logp, dlp, n * 28, hipMemcpyDeviceToHost));
+    if (logv) AZ_HIP(hipMemcpy(logv, dlv, n * 12, hipMemcpyDeviceToHost));
+    if (probs) AZ_HIP(hipMemcpy(probs, dp, n * 28, hipMemcpyDeviceToHost));
+    if (value) AZ_HIP(hipMemcpy(value, dv, n * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_net_forward_dev(az_engine* e, int64_t n, const uint64_t* states_dev, float* probs_dev, float* value_dev) {
+    AZ_CHECK_E(e);
+    if (!e->net) {
+        set_error("az_net_forward_dev: call az_net_load first");
+        return AZ_ERR_NO_NET;
+    }
+    return cnn_forward(e->net, n, states_dev, nullptr, nullptr, probs_dev, value_dev, e->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+// az_env.hip -- K1: batched environment kernels on packed bitboards (gfx950).
+//
+// Replaces, for n independent positions per launch:
+//   env_cython.pyx:76-141 (check_full, check_winner, done, valid_mask, place, step), :143-149 (current_state),
+//   :168-190 (flip, flip_action); environments/TTT/utils.py:5-45; environments/NBTTT/env.py:29-60 +
+//   NBTTT/utils.py:238-268.
+// HBM-streaming kernels: one lane per position, 16-byte (Connect4) coalesced loads/stores, grid-stride loop.
+// Algorithmic bytes per position (Connect4 step): 16 in + 4 action + 16 out + 5 status = 41 B.
+#include "az_internal.hpp"
+
+namespace az {
+
+template <class G>
+__device__ inline typename G::State load_state(const u64* p, i64 i) {
+    typename G::State s;
+    if constexpr (G::W == 2) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * i);
+        s.w[0] = v.x;
+        s.w[1] = v.y;
+    } else if constexpr (G::W == 4) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p + 4 * i);
+        ulonglong2 a = q[0], b = q[1];
+        s.w[0] = a.x;
+        s.w[1] = a.y;
+        s.w[2] = b.x;
+        s.w[3] = b.y;
+    } else {
+        s.w[0] = p[i];
+    }
+    return s;
+}
+
+template <class G>
+__device__ inline void store_state(u64* p, i64 i, const typename G::State& s) {
+    if constexpr (G::W == 2) {
+        *reinterpret_cast<ulonglong2*>(p + 2 * i) = make_ulonglong2(s.w[0], s.w[1]);
+    } else if constexpr (G::W == 4) {
+        ulonglong2* q = reinterpret_cast<ulonglong2*>(p + 4 * i);
+        q[0] = make_ulonglong2(s.w[0], s.w[1]);
+        q[1] = make_ulonglong2(s.w[2], s.w[3]);
+    } else {
+        p[i] = s.w[0];
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_env_step(i64 n, const u64* __restrict__ in, const i32* __restrict__ act,
+                                                  u64* __restrict__ out, u8* __restrict__ placed,
+                                                  i8* __restrict__ winner, u8* __restrict__ done,
+                                                  u16* __restrict__ legal) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        typename G::State s = load_state<G>(in, i);
+        bool ok = false;
+        if (act) {
+            int a = act[i];
+            ok = G::place(s, a);                       // env.place
+            if (ok) s.w[G::W - 1] ^= TURN_FLAG;        // env.switch_turn (only when placed: env.step)
+        }
+        if (out) store_state<G>(out, i, s);
+        if (placed) placed[i] = ok ? 1 : 0;
+        int w = G::winner(s);
+        if (winner) winner[i] = (i8)w;
+        if (done) done[i] = (w != 0 || G::full(s)) ? 1 : 0;
+        if (legal) legal[i] = (u16)G::legal(s);
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_env_status(i64 n, const u64* __restrict__ in, i8* __restrict__ winner,
+                                                    u8* __restrict__ done, u16* __restrict__ legal,
+                                                    u8* __restrict__ full) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        typename G::State s = load_state<G>(in, i);
+        int w = G::winner(s);
+        bool f = G::full(s);
+        if (winner) winner[i] = (i8)w;
+        if (done) done[i] = (w != 0 || f) ? 1 : 0;
+        if (legal) legal[i] = (u16)G::legal(s);
+        if (full) full[i] = f ? 1 : 0;
+    }
+}
+
+// env.current_state(): one lane per output float so stores are fully coalesced.
+__global__ __launch_bounds__(256) void k_planes_c4(i64 n, const u64* __restrict__ in, float* __restrict__ out) {
+    i64 total = n * 126;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        i64 i = t / 126;
+        int r = (int)(t - i * 126), ch = r / 42, p = r % 42, row = p / 7, col = p % 7;
+        C4::State s = load_state<C4>(in, i);
+        int bit = col * 7 + (5 - row);
+        float v;
+        if (ch == 0) v = (float)((C4::xs(s) >> bit) & 1);           // board == 1       (pyx:146)
+        else if (ch == 1) v = (float)((C4::os(s) >> bit) & 1);      // board == -1      (pyx:147)
+        else v = (float)C4::turn(s);                                // +1 / -1 plane    (pyx:148)
+        out[t] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_planes_ttt(i64 n, const u64* __restrict__ in, float* __restrict__ out) {
+    i64 total = n * 27;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        i64 i = t / 27;
+        int r = (int)(t - i * 27), ch = r / 9, p = r % 9;
+        TTT::State s = load_state<TTT>(in, i);
+        float v;
+        if (ch == 0) v = (float)((TTT::xs(s) >> p) & 1);
+        else if (ch == 1) v = (float)((TTT::os(s) >> p) & 1);
+        else v = (float)TTT::turn(s);                               // TTT/utils.py:10
+        out[t] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_planes_nbttt(i64 n, const u64* __restrict__ in, float* __restrict__ out) {
+    i64 total = n * 252;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        i64 i = t / 252;
+        int r = (int)(t - i * 252), ch = r / 9, p = r % 9;
+        NBTTT::State s = load_state<NBTTT>(in, i);
+        float v;
+        if (ch < 9) v = (float)((NBTTT::sub(s, ch) >> p) & 1);                 // X planes
+        else if (ch < 18) v = (float)((NBTTT::sub(s, ch - 9) >> (9 + p)) & 1); // O planes
+        else if (ch < 27) v = (ch - 18 == NBTTT::curr(s)) ? 1.f : 0.f;         // current-board planes (0-based)
+        else v = (float)NBTTT::turn(s);
+        out[t] = v;
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_env_flip(i64 n, const u64* __restrict__ in, u64* __restrict__ out,
+                                                  i8* __restrict__ fa) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        typename G::State s = load_state<G>(in, i);
+        if (out) store_state<G>(out, i, G::flip(s));
+        if (fa) {
+            bool sym = G::symmetric(s);
+            for (int a = 0; a < G::A; a++) fa[i * G::A + a] = (i8)G::flip_action(sym, a);
+        }
+    }
+}
+
+static inline int grid_for(i64 n) {
+    i64 b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;  // 256 CUs x 8 blocks; grid-stride the rest
+    return (int)b;
+}
+
+#define AZ_DISPATCH_GAME(game, ...)                                 \
+    switch (game) {                                                 \
+        case AZ_GAME_C4: { using GT = C4; __VA_ARGS__; } break;     \
+        case AZ_GAME_TTT: { using GT = TTT; __VA_ARGS__; } break;   \
+        case AZ_GAME_NBTTT: { using GT = NBTTT; __VA_ARGS__; } break; \
+        default: set_error("unknown game"); return AZ_ERR_ARG;      \
+    }
+
+int launch_env_step(int game, i64 n, const u64* in, const i32* act, u64* out, u8* placed, i8* winner, u8* done,
+                    u16* legal, hipStream_t st) {
+    if (n <= 0) return AZ_OK;
+    AZ_DISPATCH_GAME(game, k_env_step<GT><<<dim3(grid_for(n)), dim3(256), 0, st>>>(n, in, act, out, placed, winner, done, legal));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_env_status(int game, i64 n, const u64* in, i8* winner, u8* done, u16* legal, u8* full, hipStream_t st) {
+    if (n <= 0) return AZ_OK;
+    AZ_DISPATCH_GAME(game, k_env_status<GT><<<dim3(grid_for(n)), dim3(256), 0, st>>>(n, in, winner, done, legal, full));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_env_planes(int game, i64 n, const u64* in, float* planes, hipStream_t st) {
+    if (n <= 0) return AZ_OK;
+    if (game == AZ_GAME_C4) k_planes_c4<<<dim3(grid_for(n * 126)), dim3(256), 0, st>>>(n, in, planes);
+    else if (game == AZ_GAME_TTT) k_planes_ttt<<<dim3(grid_for(n * 27)), dim3(256), 0, st>>>(n, in, planes);
+    else if (game == AZ_GAME_NBTTT) k_planes_nbttt<<<dim3(grid_for(n * 252)), dim3(256), 0, st>>>(n, in, planes);
+    else { set_error("unknown game"); return AZ_ERR_ARG; }
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_env_flip(int game, i64 n, const u64* in, u64* out, i8* fa, hipStream_t st) {
+    if (n <= 0) return AZ_OK;
+    AZ_DISPATCH_GAME(game, k_env_flip<GT><<<dim3(grid_for(n)), dim3(256), 0, st>>>(n, in, out, fa));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+}  // namespace az

@@ -1,0 +1,37 @@
+// az_play.hpp -- device-side buffers of the self-play collector (K4) shared by az_play.hip and az_engine.hip.
+#pragma once
+#include "az_internal.hpp"
+
+namespace az {
+
+struct Play {
+    // per-slot staging of the game in progress: [G][MAX_PLIES]
+    u64* tj_state;   // [..][W]
+    float* tj_pi;    // [..][A]
+    i8* tj_action;
+    i8* tj_player;
+    // committed (finished) games, in completion order: [out_cap] plies
+    i64 out_cap;
+    u64* out_state;  // [out_cap][W]
+    float* out_pi;   // [out_cap][A]
+    float* out_z;
+    i8* out_player;
+    i8* out_action;
+    u8* out_done;
+    u64* out_gid;
+    unsigned long long* out_count;      // plies committed
+    unsigned long long* out_games;      // games committed
+    unsigned long long* games_started;  // refill counter
+};
+
+int launch_choose(const Dev& d, const Play& p, const double* temps, double temp_all, int first_n, int move_mode,
+                  i32* actions, float* pi, hipStream_t st);
+int launch_advance(const Dev& d, const Play& p, const i32* actions, const float* pi, int reuse, int record,
+                   hipStream_t st);
+int launch_refill(const Dev& d, const Play& p, unsigned long long target, u64 gid_base, hipStream_t st);
+int launch_init_slots(const Dev& d, int use_openings, u64 gid_base, hipStream_t st);
+int launch_traj_pack(int game, const Play& p, i64 n, u8* out, hipStream_t st);
+int launch_traj_unpack(int game, i64 n, const u8* recs, float* state, float* prob, float* value, i32* winner,
+                       float* next_state, u8* done, hipStream_t st);
+
+}  // namespace az

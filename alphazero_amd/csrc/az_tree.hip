@@ -1,0 +1,528 @@
+// az_tree.hip -- K2: batched PUCT select / expand / backup over per-game node arenas in HBM (gfx950).
+//
+// Replaces the reference's Python tree for G games at once:
+//   TreeNode            MCTS.py:10-19     -> 16-byte node record (az_internal.hpp), children contiguous in insertion order
+//   TreeNode.PUCT       MCTS.py:47-55     -> puct_score(): the exact float32 rounding sequence, no FMA contraction
+//   TreeNode.select     MCTS.py:79-80     -> one lane per child, sub-wave butterfly arg-max, ties -> lowest insertion index
+//   select_leaf_node    MCTS.py:108-113   -> walk(): one coalesced 16-byte load per lane per level, env.step on bitboards
+//   MCTS_AZ.playout     MCTS.py:139-164   -> leaf_prepare() + finish(): flip, mask + renormalise priors, expand, terminal value
+//   TreeNode.expand     MCTS.py:71-77     -> bump allocation of k child records, one lane per child
+//   TreeNode.update     MCTS.py:82-87     -> backup from the path staged in LDS: float32 running mean, alternating sign
+//
+// Work decomposition: one sub-wave GROUP of LG lanes (8 for Connect4, 16 for TTT/NBTTT) owns one game; a 256-thread
+// block holds 256/LG games.  Groups never talk to each other, a game is only ever touched by its own group, and a
+// group lives inside one wavefront, so all tree reads/writes of a game are wavefront-ordered.
+//
+// This file must be compiled with -ffp-contract=off and correctly rounded f32 divide/sqrt (see Makefile).
+#include "az_internal.hpp"
+
+namespace az {
+
+__device__ inline float as_f(u32 x) { return __uint_as_float(x); }
+__device__ inline u32 as_u(float x) { return __float_as_uint(x); }
+
+// MCTS.py:47-55.  tab = {f32(c_init + ln((1+Np+c_base)/c_base)), f32(sqrt(Np))}, built on the host in float64.
+__device__ inline float puct_score(u32 n, float Q, float P, float2 tab) {
+    float pr = 0.75f * P;   // (1 - eps) * prior
+    float nz = 0.25f * P;   // eps * noise   (noise == prior in eval mode; train mode stores the mix in P)
+    float p = pr + nz;
+    if (n == 0) return INFINITY;  // first-play urgency: u = inf  (MCTS.py:50-51)
+    float t = tab.x * p;
+    t = t * tab.y;
+    float u = t / (float)(1u + n);
+    return -Q + u;
+}
+
+__device__ inline float2 tab_lookup(const Dev& d, u32 Np) {
+    if (Np < (u32)d.tab_n) return d.tab[Np];
+    atomicOr(d.err, 2u);  // table too short: fall back to device libm (not covered by the bit-exact contract)
+    double A = d.c_init + log((double)(1u + Np + (u32)d.c_base) / (double)d.c_base);
+    return make_float2((float)A, (float)sqrt((double)Np));
+}
+
+template <class G>
+__device__ inline typename G::State load_root_state(const Dev& d, int g) {
+    typename G::State s;
+#pragma unroll
+    for (int i = 0; i < G::W; i++) s.w[i] = d.root_state[(i64)g * G::W + i];
+    return s;
+}
+
+// Synthetic evaluators (see oracle/az_oracle.c orc_eval_hash for the specification).
+template <class G>
+__device__ inline void eval_synthetic(int kind, u64 seed, const typename G::State& aug, float* probs, float& value) {
+    if (kind == AZ_EVAL_UNIFORM) {
+        const float p = 1.0f / (float)G::A;
+#pragma unroll
+        for (int a = 0; a < G::A; a++) probs[a] = p;
+        value = 0.f;
+    } else {
+        u64 h = seed;
+#pragma unroll
+        for (int i = 0; i < G::W; i++) h = mix64(h ^ aug.w[i]);
+        float raw[G::A];
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < G::A; a++) {
+            raw[a] = (float)((mix64(h + (u64)a + 1) >> 40) + 1) * (1.0f / 16777216.0f);
+            s = s + raw[a];
+        }
+#pragma unroll
+        for (int a = 0; a < G::A; a++) probs[a] = raw[a] / s;
+        value = (float)(mix64(h + 64) >> 40) * (1.0f / 8388608.0f) - 1.0f;
+    }
+}
+
+// Counter-based uniform in [0,1) keyed by (seed, game id, playout counter, stream).
+__device__ inline float rng_uniform(u64 seed, u64 gid, u64 ctr, u32 stream) {
+    u64 h = mix64(seed ^ mix64(gid * 0x9E3779B97F4A7C15ull + ctr) ^ ((u64)stream << 32));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+// Gamma(alpha, 1) sample, Marsaglia-Tsang with the alpha<1 boost; statistical parity only (np.random.dirichlet,
+// MCTS.py:156).  Each child lane draws its own variate from its own counter stream.
+__device__ inline float rng_gamma(float alpha, u64 seed, u64 gid, u64 ctr, u32 lane) {
+    float a = alpha < 1.f ? alpha + 1.f : alpha;
+    float dd = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * dd), x = dd;
+    for (u32 it = 0; it < 32; it++) {
+        float u1 = rng_uniform(seed, gid, ctr, 0x100u + lane * 128u + it * 3u);
+        float u2 = rng_uniform(seed, gid, ctr, 0x101u + lane * 128u + it * 3u);
+        float u3 = rng_uniform(seed, gid, ctr, 0x102u + lane * 128u + it * 3u);
+        float n = sqrtf(-2.f * logf(u1 + 5.9604645e-8f)) * cosf(6.2831853f * u2);  // Box-Muller
+        float v = 1.f + c * n;
+        if (v <= 0.f) continue;
+        v = v * v * v;
+        if (logf(u3 + 5.9604645e-8f) < 0.5f * n * n + dd - dd * v + dd * logf(v)) {
+            x = dd * v;
+            break;
+        }
+    }
+    if (alpha < 1.f) {
+        float u = rng_uniform(seed, gid, ctr, 0x1000u + lane);
+        x *= powf(u + 5.9604645e-8f, 1.f / alpha);
+    }
+    return x;
+}
+
+template <int LG>
+__device__ inline int group_argmax_first(float score, int gl) {
+    int idx = gl;
+#pragma unroll
+    for (int m = LG / 2; m >= 1; m >>= 1) {
+        float os = __shfl_xor(score, m, LG);
+        int oi = __shfl_xor(idx, m, LG);
+        if (os > score || (os == score && oi < idx)) {
+            score = os;
+            idx = oi;
+        }
+    }
+    return idx;
+}
+
+template <int LG>
+__device__ inline float group_sum(float v) {
+#pragma unroll
+    for (int m = LG / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LG);
+    return v;
+}
+
+struct Leaf {
+    u32 node;      // arena index of the leaf
+    int depth;     // levels walked (path has depth+1 entries)
+    u32 link;      // the leaf's link word (no children yet; action nibble set)
+    u32 flags;     // bit0 terminal, bit1 flipped, bit2 unflipped board mirror-symmetric
+    float tvalue;  // terminal value
+};
+
+// MCTS.py:108-113 (select_leaf_node) for one game.  Stages (index, N, Q) of every node on the path in LDS.
+template <class G>
+__device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State& s, u32 root, u32 rN, float rQ,
+                            u32 rlink, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+    constexpr int LG = G::LG;
+    u32 node = root, Np = rN, link = rlink;
+    int depth = 0;
+    if (gl == 0) {
+        p_idx[0] = root;
+        p_N[0] = rN;
+        p_Q[0] = rQ;
+    }
+    while (link_nchild(link) > 0 && depth < G::MAXD - 1) {
+        u32 k = link_nchild(link), first = link_first(link);
+        float2 tb = tab_lookup(d, Np);
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        float score = -INFINITY;
+        if ((u32)gl < k) {
+            rec = nodes[first + gl];  // one coalesced 16-byte load per child lane
+            score = puct_score(rec.x, as_f(rec.y), as_f(rec.z), tb);
+        }
+        int best = group_argmax_first<LG>(score, gl);
+        u32 cN = __shfl(rec.x, best, LG);
+        u32 cQ = __shfl(rec.y, best, LG);
+        u32 cl = __shfl(rec.w, best, LG);
+        node = first + (u32)best;
+        depth++;
+        if (gl == 0) {
+            p_idx[depth] = node;
+            p_N[depth] = cN;
+            p_Q[depth] = as_f(cQ);
+        }
+        G::step(s, (int)link_action(cl));  // env.step(action), redundantly on every lane of the group
+        Np = cN;
+        link = cl;
+    }
+    Leaf lf;
+    lf.node = node;
+    lf.link = link;
+    lf.depth = depth;
+    lf.flags = 0;
+    lf.tvalue = 0.f;
+    return lf;
+}
+
+// MCTS.py:142 + :154-163 -- draw the flip bit (always, like np.random.rand()), classify the leaf, build the
+// position the evaluator sees.
+template <class G>
+__device__ inline void leaf_prepare(const Dev& d, int g, const typename G::State& s, typename G::State& aug, Leaf& lf,
+                                    u32& fpos, u64 ctr) {
+    bool flipped = false;
+    if constexpr (G::CAN_FLIP) {
+        if (d.flip_mode == AZ_FLIP_STREAM) {
+            flipped = (fpos < (u64)d.flip_n) ? (d.flip_bits[(i64)g * d.flip_n + fpos] != 0) : false;
+            fpos++;
+        } else if (d.flip_mode == AZ_FLIP_RANDOM) {
+            flipped = rng_uniform(d.rng_seed, d.game_id[g], ctr, 1u) < 0.5f;
+        }
+    }
+    int w = G::winner(s);
+    bool term = (w != 0) || G::full(s);
+    aug = flipped ? G::flip(s) : s;
+    lf.flags = (term ? 1u : 0u) | (flipped ? 2u : 0u) | (G::symmetric(s) ? 4u : 0u);
+    lf.tvalue = (w == 0) ? 0.f : ((w == G::turn(s)) ? 1.f : -1.f);  // MCTS.py:159-163
+}
+
+// MCTS.py:147-157 (mask, renormalise, remap, expand) + :164 (update).  probs[] are over ALL actions of the
+// evaluated (possibly mirrored) position; returns the updated root (N, Q, link) through references.
+template <class G>
+__device__ inline void finish(const Dev& d, int g, uint4* nodes, const typename G::State& aug, const Leaf& lf,
+                              const float* probs, float value, int gl, u32& nalloc, u32 root, u32& rN, float& rQ,
+                              u32& rlink, const u32* p_idx, const u32* p_N, const float* p_Q, u64 ctr, u32& st_children) {
+    constexpr int LG = G::LG;
+    const bool term = lf.flags & 1u, flipped = lf.flags & 2u, sym = lf.flags & 4u;
+    float v = lf.tvalue;
+    if (!term) {
+        v = value;
+        u32 legal = G::legal(aug);  // env_aug.valid_move()
+        int nv = 0, myact = -1;
+        float s = 0.f, myp = 0.f;
+#pragma unroll
+        for (int a = 0; a < G::A; a++) {
+            if ((legal >> a) & 1u) {
+                float pa = probs[a];
+                s = s + pa;  // sum(probs): left-to-right float32 over the evaluated env's ascending legal actions
+                if (nv == gl) {
+                    myp = pa;
+                    myact = a;
+                }
+                nv++;
+            }
+        }
+        float prior = myp / s;  // probs /= sum(probs)
+        if (d.noise_alpha > 0.f) {  // train(): Dirichlet at every expansion, mixed 0.75/0.25 (MCTS.py:48-49,155-157)
+            float gsample = (gl < nv) ? rng_gamma(d.noise_alpha, d.rng_seed, d.game_id[g], ctr, (u32)gl) : 0.f;
+            float tot = group_sum<LG>(gsample);
+            float noise = tot > 0.f ? gsample / tot : 1.0f / (float)nv;
+            prior = 0.75f * prior + 0.25f * noise;
+        }
+        if (flipped) myact = G::flip_action(sym, myact);  // MCTS.py:152-153
+        u32 first = nalloc;
+        if ((i64)first + nv <= d.cap && first + (u32)nv <= LINK_FIRST_MASK) {
+            if (gl < nv) nodes[first + gl] = make_uint4(0u, 0u, as_u(prior), (u32)myact << 28);
+            u32 nl = (lf.link & 0xF0000000u) | first | ((u32)nv << 24);  // keep the leaf's own action nibble
+            if (gl == 0) reinterpret_cast<u32*>(&nodes[lf.node])[3] = nl;
+            if (lf.node == root) rlink = nl;
+            nalloc = first + (u32)nv;
+            st_children += (u32)nv;
+        } else {
+            atomicOr(d.err, 1u);  // arena overflow: the leaf stays a leaf
+        }
+    }
+    // TreeNode.update (MCTS.py:82-87): n += 1; Q += (v - Q) / n, sign alternating towards the root.
+    const int depth = lf.depth;
+    for (int dd = gl; dd <= depth; dd += LG) {
+        u32 idx = p_idx[dd], N = p_N[dd];
+        float Q = p_Q[dd];
+        float val = ((depth - dd) & 1) ? -v : v;
+        u32 N1 = N + 1u;
+        float dq = val - Q;
+        dq = dq / (float)N1;
+        float Q1 = Q + dq;
+        *reinterpret_cast<uint2*>(&nodes[idx]) = make_uint2(N1, as_u(Q1));
+    }
+    {  // the root's new statistics, kept in registers by every lane for the next playout
+        float val = (depth & 1) ? -v : v;
+        u32 N1 = rN + 1u;
+        float dq = val - rQ;
+        dq = dq / (float)N1;
+        rQ = rQ + dq;
+        rN = N1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused search: n_sims complete playouts per game in ONE launch (evaluator computed in-kernel).
+// ------------------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(256) void k_search_fused(Dev d, int n_sims) {
+    constexpr int LG = G::LG, GPB = 256 / LG;
+    __shared__ u32 s_idx[GPB][G::MAXD];
+    __shared__ u32 s_N[GPB][G::MAXD];
+    __shared__ float s_Q[GPB][G::MAXD];
+    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int g = blockIdx.x * GPB + grp;
+    if (g >= d.G) return;
+    if (!d.active[g]) return;
+    uint4* nodes = d.nodes + (i64)g * d.cap;
+    const typename G::State rs = load_root_state<G>(d, g);
+    const u32 root = d.root[g];
+    u32 nalloc = d.n_alloc[g];
+    uint4 rr = nodes[root];
+    u32 rN = rr.x, rlink = rr.w;
+    float rQ = as_f(rr.y);
+    u32 fpos = d.flip_pos[g];
+    u64 ctr = d.sim_ctr[g];
+    u32 st_levels = 0, st_evals = 0, st_term = 0, st_children = 0;
+    for (int sim = 0; sim < n_sims; sim++) {
+        typename G::State s = rs;  // env.copy()
+        Leaf lf = walk<G>(d, nodes, s, root, rN, rQ, rlink, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+        typename G::State aug;
+        leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+        float probs[G::A], value = 0.f;
+        if (!(lf.flags & 1u)) {
+            eval_synthetic<G>(d.evaluator, d.eval_seed, aug, probs, value);
+            st_evals++;
+        } else {
+#pragma unroll
+            for (int a = 0; a < G::A; a++) probs[a] = 0.f;
+            st_term++;
+        }
+        finish<G>(d, g, nodes, aug, lf, probs, value, gl, nalloc, root, rN, rQ, rlink, s_idx[grp], s_N[grp], s_Q[grp],
+                  ctr, st_children);
+        st_levels += (u32)lf.depth;
+        ctr++;
+    }
+    if (gl == 0) {
+        d.n_alloc[g] = nalloc;
+        d.flip_pos[g] = fpos;
+        d.sim_ctr[g] = ctr;
+        atomicAdd(&d.stats[ST_PLAYOUTS], (unsigned long long)n_sims);
+        atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)st_levels);
+        atomicAdd(&d.stats[ST_EVALS], (unsigned long long)st_evals);
+        atomicAdd(&d.stats[ST_TERMINAL], (unsigned long long)st_term);
+        atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split search: select -> (evaluator kernel or host) -> backup, one playout per game per round.
+// ------------------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(256) void k_select(Dev d) {
+    constexpr int LG = G::LG, GPB = 256 / LG;
+    __shared__ u32 s_idx[GPB][G::MAXD];
+    __shared__ u32 s_N[GPB][G::MAXD];
+    __shared__ float s_Q[GPB][G::MAXD];
+    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int g = blockIdx.x * GPB + grp;
+    if (g >= d.G) return;
+    if (!d.active[g]) {
+        if (gl == 0) d.leaf_flags[g] = 0u;
+        return;
+    }
+    const uint4* nodes = d.nodes + (i64)g * d.cap;
+    typename G::State s = load_root_state<G>(d, g);
+    const u32 root = d.root[g];
+    uint4 rr = nodes[root];
+    Leaf lf = walk<G>(d, nodes, s, root, rr.x, as_f(rr.y), rr.w, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    typename G::State aug;
+    u32 fpos = d.flip_pos[g];
+    u64 ctr = d.sim_ctr[g];
+    leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+    for (int dd = gl; dd <= lf.depth; dd += LG) {  // path: LDS -> HBM, coalesced
+        d.path_idx[(i64)g * G::MAXD + dd] = s_idx[grp][dd];
+        d.path_N[(i64)g * G::MAXD + dd] = s_N[grp][dd];
+        d.path_Q[(i64)g * G::MAXD + dd] = s_Q[grp][dd];
+    }
+    if (gl == 0) {
+#pragma unroll
+        for (int i = 0; i < G::W; i++) d.leaf_state[(i64)g * G::W + i] = aug.w[i];
+        d.leaf_depth[g] = lf.depth;
+        d.leaf_flags[g] = lf.flags | 8u;
+        d.leaf_tvalue[g] = lf.tvalue;
+        d.flip_pos[g] = fpos;
+        if (!(lf.flags & 1u)) {
+            u32 pos = atomicAdd(d.eval_count, 1u);  // compaction: only non-terminal leaves reach the network
+            d.eval_list[pos] = (u32)g;
+        }
+        atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_backup(Dev d) {
+    constexpr int LG = G::LG, GPB = 256 / LG;
+    __shared__ u32 s_idx[GPB][G::MAXD];
+    __shared__ u32 s_N[GPB][G::MAXD];
+    __shared__ float s_Q[GPB][G::MAXD];
+    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int g = blockIdx.x * GPB + grp;
+    if (g >= d.G) return;
+    const u32 flags = d.leaf_flags[g];
+    if (!(flags & 8u)) return;
+    uint4* nodes = d.nodes + (i64)g * d.cap;
+    Leaf lf;
+    lf.depth = d.leaf_depth[g];
+    lf.flags = flags & 7u;
+    lf.tvalue = d.leaf_tvalue[g];
+    for (int dd = gl; dd <= lf.depth; dd += LG) {  // path: HBM -> LDS
+        s_idx[grp][dd] = d.path_idx[(i64)g * G::MAXD + dd];
+        s_N[grp][dd] = d.path_N[(i64)g * G::MAXD + dd];
+        s_Q[grp][dd] = d.path_Q[(i64)g * G::MAXD + dd];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    lf.node = s_idx[grp][lf.depth];
+    lf.link = nodes[lf.node].w;
+    typename G::State aug;
+#pragma unroll
+    for (int i = 0; i < G::W; i++) aug.w[i] = d.leaf_state[(i64)g * G::W + i];
+    float probs[G::A], value = 0.f;
+    if (!(flags & 1u)) {
+#pragma unroll
+        for (int a = 0; a < G::A; a++) probs[a] = d.eval_probs[(i64)g * G::A + a];
+        value = d.eval_value[g];
+    } else {
+#pragma unroll
+        for (int a = 0; a < G::A; a++) probs[a] = 0.f;
+    }
+    const u32 root = d.root[g];
+    u32 nalloc = d.n_alloc[g];
+    u32 rN = s_N[grp][0], rlink = nodes[root].w;
+    float rQ = s_Q[grp][0];
+    u32 st_children = 0;
+    u64 ctr = d.sim_ctr[g];
+    finish<G>(d, g, nodes, aug, lf, probs, value, gl, nalloc, root, rN, rQ, rlink, s_idx[grp], s_N[grp], s_Q[grp], ctr,
+              st_children);
+    if (gl == 0) {
+        d.n_alloc[g] = nalloc;
+        d.sim_ctr[g] = ctr + 1;
+        d.leaf_flags[g] = 0u;
+        atomicAdd(&d.stats[ST_PLAYOUTS], 1ull);
+        atomicAdd(&d.stats[(flags & 1u) ? ST_TERMINAL : ST_EVALS], 1ull);
+        atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
+    }
+}
+
+// (action, visits, Q, prior) of the root children in insertion order: MCTS.py:170-171.
+template <class G>
+__global__ __launch_bounds__(256) void k_root_children(Dev d, i32* actions, i32* visits, float* q, float* prior,
+                                                      i32* nch, i32* rootN, float* rootQ) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    const uint4* nodes = d.nodes + (i64)g * d.cap;
+    uint4 rr = nodes[d.root[g]];
+    u32 k = link_nchild(rr.w), first = link_first(rr.w);
+    if (nch) nch[g] = (i32)k;
+    if (rootN) rootN[g] = (i32)rr.x;
+    if (rootQ) rootQ[g] = as_f(rr.y);
+    for (int i = 0; i < G::A; i++) {
+        uint4 c = (u32)i < k ? nodes[first + i] : make_uint4(0u, 0u, 0u, 0xF0000000u);
+        if (actions) actions[(i64)g * G::A + i] = (u32)i < k ? (i32)link_action(c.w) : -1;
+        if (visits) visits[(i64)g * G::A + i] = (i32)c.x;
+        if (q) q[(i64)g * G::A + i] = as_f(c.y);
+        if (prior) prior[(i64)g * G::A + i] = as_f(c.z);
+    }
+}
+
+// MCTS.py:92,135: TreeNode(None, 1) -- fresh single-node tree for every (selected) slot.
+__global__ __launch_bounds__(256) void k_reset_trees(Dev d, const u8* only) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    if (only && !only[g]) return;
+    d.nodes[(i64)g * d.cap] = make_uint4(0u, 0u, as_u(1.0f), 0u);
+    d.root[g] = 0u;
+    d.n_alloc[g] = 1u;
+    d.leaf_flags[g] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_puct(i64 n, const i32* Np, const i32* nv, const float* Q, const float* P,
+                                              const float2* tab, i32 tab_n, double c_init, i32 c_base, float* score) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 np = (u32)Np[i];
+    float2 tb;
+    if (np < (u32)tab_n) tb = tab[np];
+    else {
+        double A = c_init + log((double)(1u + np + (u32)c_base) / (double)c_base);
+        tb = make_float2((float)A, (float)sqrt((double)np));
+    }
+    score[i] = puct_score((u32)nv[i], Q[i], P[i], tb);
+}
+
+#define AZ_DISPATCH_GAME(game, ...)                                 \
+    switch (game) {                                                 \
+        case AZ_GAME_C4: { using GT = C4; __VA_ARGS__; } break;     \
+        case AZ_GAME_TTT: { using GT = TTT; __VA_ARGS__; } break;   \
+        case AZ_GAME_NBTTT: { using GT = NBTTT; __VA_ARGS__; } break; \
+        default: set_error("unknown game"); return AZ_ERR_ARG;      \
+    }
+
+static inline int game_of(const Dev& d) { return d.game; }
+
+int launch_search_fused(const Dev& d, int n_sims, hipStream_t st) {
+    AZ_DISPATCH_GAME(game_of(d), {
+        int gpb = 256 / GT::LG;
+        k_search_fused<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d, n_sims);
+    });
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_select(const Dev& d, hipStream_t st) {
+    AZ_HIP(hipMemsetAsync(d.eval_count, 0, sizeof(u32), st));
+    AZ_DISPATCH_GAME(game_of(d), {
+        int gpb = 256 / GT::LG;
+        k_select<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
+    });
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_backup(const Dev& d, hipStream_t st) {
+    AZ_DISPATCH_GAME(game_of(d), {
+        int gpb = 256 / GT::LG;
+        k_backup<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
+    });
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,
+                         float* rootQ, hipStream_t st) {
+    AZ_DISPATCH_GAME(game_of(d), k_root_children<GT><<<dim3((d.G + 255) / 256), dim3(256), 0, st>>>(d, actions, visits, q, prior, nch, rootN, rootQ));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_reset_trees(const Dev& d, const u8* only, hipStream_t st) {
+    k_reset_trees<<<dim3((d.G + 255) / 256), dim3(256), 0, st>>>(d, only);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_puct(double c_init, i32 c_base, i64 n, const i32* Np, const i32* nv, const float* Q, const float* P,
+                const float2* tab, i32 tab_n, float* score, hipStream_t st) {
+    k_puct<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, Np, nv, Q, P, tab, tab_n, c_init, c_base, score);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+}  // namespace az
