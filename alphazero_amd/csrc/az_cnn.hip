@@ -1,9 +1,455 @@
-// placeholder until the MFMA kernel lands (next commit)
+// az_cnn.hip -- K3: the Connect4 policy/value CNN, one fused kernel per leaf batch on fp32 MFMA (gfx950).
+//
+// Replaces CNN.forward / CNN.predict (environments/Connect4/Network.py:16-27,60-64,78-85) evaluated at batch 1 per
+// playout (MCTS.py:145-146) by ONE launch per batch of leaves:
+//   planes from bitboards -> stem conv3x3(3->128)+BN+SiLU -> 3 x Block[conv3x3+BN+SiLU -> conv1x1+BN, +x, SiLU]
+//   -> policy head conv1x1(128->3)+BN+SiLU+Linear(126->7)+log-softmax, value head conv1x1(128->1)+BN+SiLU+Linear(42->3)
+//   +log-softmax -> probs = exp(logp), v = -player*0.5*P(draw) + P(win) - P(lose).
+// Eval mode: Dropout2d is the identity, BatchNorm uses running stats and is folded into the conv weights on the host.
+//
+// Mapping to CDNA4.  Implicit GEMM, TRANSPOSED: out^T[co][pos] = W[co][k] * act^T[k][pos], k = (tap, ci).
+//   * M = 128 output channels (4 tiles of 32), N = board positions of 3 samples (126 of 128 columns, 4 tiles of 32),
+//     one workgroup = 4 waves, wave w owns N-tile w and all 4 M-tiles  -> 16 f32x16 accumulator tiles per workgroup.
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (the 1e-4 contract rules out bf16), 64 FLOP/clk/SIMD.
+//   * A operand (weights): pre-swizzled on the host into the exact per-lane order, one coalesced 16-byte load per
+//     lane per k-pair (all 4 M-tiles), streamed from L2 (2 MB of weights stay resident in every XCD's 4 MB L2),
+//     software-prefetched PF k-pairs ahead.  No LDS staging: every weight is used by one MFMA per wave.
+//   * B operand (activations): LDS image [ci][pos] (72 KB, 2 workgroups per CU); a 3x3 tap is a constant address
+//     shift plus a per-lane validity bit (zero padding), so the im2col matrix is never materialised.
+//   * conv3x3 -> conv1x1 chaining without LDS: the accumulator tile (row = co on registers, column = pos on lanes)
+//     IS the B operand of the next product when the reduction index is taken in the order (r, r+4): see conv1().
+//   * Activations never leave the CU; HBM traffic per leaf = 16 B in + 32 B out.
+// FLOPs per leaf: 41.62 MFLOP.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
 #include "az_cnn.hpp"
+
 namespace az {
-struct Cnn { int dummy; };
-int cnn_create(const float*, size_t, int, Cnn**) { set_error("CNN kernel not built yet"); return AZ_ERR_NO_NET; }
-void cnn_destroy(Cnn*) {}
-int cnn_forward(Cnn*, i64, const u64*, float*, float*, float*, float*, hipStream_t) { return AZ_ERR_NO_NET; }
-int cnn_eval_leaves(Cnn*, const Dev&, hipStream_t) { return AZ_ERR_NO_NET; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 128;           // channels
+constexpr int NPOS = 42;          // board cells
+constexpr int SPB = 3;            // samples per workgroup
+constexpr int XS = 144;           // LDS row stride in floats: 8 guard | 128 positions | 8 guard
+constexpr int XOFF = 8;
+constexpr int PF = 8;             // weight prefetch depth (k-pairs)
+constexpr float BN_EPS = 1e-5f;
+
+struct CnnDev {
+    const float4* w_stem;      // [18][64]
+    const float4* w3[3];       // [576][64]
+    const float4* w1[3];       // [64][64]
+    const float* w_head;       // [64][64]
+    const float* b_stem;       // [128]
+    const float* b3[3];
+    const float* b1[3];
+    const float* b_head;       // [4]  policy conv BN bias (3) + value conv BN bias (1)
+    const float* plin_w;       // [7][126]
+    const float* plin_b;       // [7]
+    const float* vlin_w;       // [3][42]
+    const float* vlin_b;       // [3]
+};
+
+struct Cnn {
+    CnnDev d;
+    std::vector<void*> allocs;
+};
+
+// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) are far inside the 1e-4 contract.
+__device__ inline float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// co handled by (M-tile mt, accumulator register r, lane half h): the C/D layout of v_mfma_f32_32x32x2_f32.
+__device__ inline int co_of(int mt, int r, int h) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One 3x3 (or stem) convolution for this wave's 32 positions x 128 output channels.
+//   NKP2 = k-pairs per tap (64 for 128 input channels, 2 for the 4-plane stem image)
+template <int NKP2>
+__device__ inline void conv3(const float4* __restrict__ wA, const float* xs, int lane, int pbase, u32 tapmask,
+                             f32x16 (&acc)[4]) {
+    const int h = lane >> 5;
+    const float* bptr = xs + h * XS + XOFF + pbase;
+    const float4* wl = wA + lane;
+    constexpr int NK = 9 * NKP2;
+    constexpr int U = (NKP2 >= PF) ? PF : NKP2;
+    float4 cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = wl[(size_t)u * 64];
+    for (int k0 = 0; k0 < NK; k0 += U) {
+        const bool more = (k0 + U) < NK;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) nxt[u] = wl[(size_t)(k0 + U + u) * 64];
+        }
+        const int tap = k0 / NKP2;           // U divides NKP2: one tap per block of U k-pairs
+        const int dr = tap / 3 - 1, dc = tap % 3 - 1;
+        const bool valid = (tapmask >> tap) & 1u;
+        const float* bp = bptr + dr * 7 + dc + (k0 % NKP2) * 2 * XS;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float b = bp[u * 2 * XS];
+            b = valid ? b : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].x, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].y, b, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].z, b, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].w, b, acc[3], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = nxt[u];
+        }
+    }
 }
+
+// 1x1 convolution whose input is an accumulator-layout tile set held in registers (hin[mt][r]).
+// k-pair (mt, r) covers input channels co_of(mt, r, 0) [lanes 0-31] and co_of(mt, r, 1) [lanes 32-63]: exactly what
+// each lane half already holds, so the register IS the B operand; the host lays the weights out to match.
+__device__ inline void conv1(const float4* __restrict__ wB, const f32x16 (&hin)[4], int lane, f32x16 (&acc)[4]) {
+    const float4* wl = wB + lane;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        float4 a[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = wl[(size_t)(mt * 16 + r) * 64];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float b = hin[mt][r];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b, acc[3], 0, 0, 0);
+        }
+    }
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// n_ptr != null: the batch size is read from device memory (leaf compaction count) and `list` maps batch index ->
+// slot; outputs/inputs are then indexed by slot.
+__global__ __launch_bounds__(256, 2) void k_cnn_forward(CnnDev w, i64 n_host, const u32* __restrict__ n_ptr,
+                                                        const u32* __restrict__ list, const u64* __restrict__ states,
+                                                        float* __restrict__ logp, float* __restrict__ logv,
+                                                        float* __restrict__ probs, float* __restrict__ value) {
+    __shared__ float xs[HD * XS];      // activations [ci][pos]
+    __shared__ float x0[4 * XS];       // input planes (4th plane = 0)
+    __shared__ float hb[4 * 128];      // head conv outputs [c][pos]
+    __shared__ float s_player[SPB];
+    __shared__ long long s_slot[SPB];
+    const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
+    const i64 s0 = (i64)blockIdx.x * SPB;
+    if (s0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+
+    // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149) ----
+    if (tid < 128) {
+        const int p = tid, s = p / NPOS, q = p % NPOS, row = q / 7, col = q % 7;
+        float vx = 0.f, vo = 0.f, vt = 0.f;
+        if (p < SPB * NPOS && s0 + s < n) {
+            const i64 slot = list ? (i64)list[s0 + s] : (s0 + s);
+            const u64 w0 = states[slot * 2], w1 = states[slot * 2 + 1];
+            const int bit = col * 7 + (5 - row);
+            vx = (float)((w0 >> bit) & 1ull);
+            vo = (float)((w1 >> bit) & 1ull);
+            vt = (w1 >> 63) ? -1.f : 1.f;
+            if (q == 0) {
+                s_player[s] = vt;
+                s_slot[s] = slot;
+            }
+        }
+        x0[0 * XS + XOFF + p] = vx;
+        x0[1 * XS + XOFF + p] = vo;
+        x0[2 * XS + XOFF + p] = vt;
+        x0[3 * XS + XOFF + p] = 0.f;
+    }
+    // per-lane geometry of this wave's N-tile: position, 3x3 validity mask (zero padding = masked taps)
+    const int pbase = wave * 32 + (lane & 31);
+    u32 tapmask = 0;
+    {
+        const int q = pbase % NPOS, row = q / 7, col = q % 7;
+        if (pbase < SPB * NPOS)
+            for (int t = 0; t < 9; t++) {
+                int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
+                if (rr >= 0 && rr < 6 && cc >= 0 && cc < 7) tapmask |= 1u << t;
+            }
+    }
+    __syncthreads();
+
+    f32x16 acc[4], acc2[4];
+    // ---- stem: conv3x3(3->128) + BN + SiLU  (Network.py:33-36) ----
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x16)(0.f);
+    conv3<2>(w.w_stem, x0, lane, pbase, tapmask, acc);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co_of(mt, r, h);
+            xs[co * XS + XOFF + pbase] = silu(acc[mt][r] + w.b_stem[co]);
+        }
+    __syncthreads();
+
+    // ---- 3 residual blocks (Network.py:16-27) ----
+#pragma unroll 1
+    for (int blk = 0; blk < 3; blk++) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x16)(0.f);
+        conv3<64>(w.w3[blk], xs, lane, pbase, tapmask, acc);
+        const float* b3 = w.b3[blk];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][r] = silu(acc[mt][r] + b3[co_of(mt, r, h)]);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc2[mt] = (f32x16)(0.f);
+        conv1(w.w1[blk], acc, lane, acc2);
+        const float* b1 = w.b1[blk];
+        __syncthreads();  // every wave has finished READING xs for this block's conv3x3
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co_of(mt, r, h);
+                float v = silu(xs[co * XS + XOFF + pbase] + acc2[mt][r] + b1[co]);  // F.silu(x + conv(x))
+                acc2[mt][r] = v;
+                xs[co * XS + XOFF + pbase] = v;
+            }
+        __syncthreads();
+    }
+
+    // ---- heads: conv1x1(128->3)+BN+SiLU and conv1x1(128->1)+BN+SiLU as ONE 32-row MFMA tile (rows 0..3 used) ----
+    {
+        f32x16 hacc = (f32x16)(0.f);
+        const float* wl = w.w_head + lane;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(size_t)(mt * 16 + r) * 64], acc2[mt][r], hacc, 0, 0, 0);
+        if (h == 0) {  // rows 0..3 live in registers 0..3 of lanes 0..31
+            hb[0 * 128 + pbase] = silu(hacc[0] + w.b_head[0]);
+            hb[1 * 128 + pbase] = silu(hacc[1] + w.b_head[1]);
+            hb[2 * 128 + pbase] = silu(hacc[2] + w.b_head[2]);
+            hb[3 * 128 + pbase] = silu(hacc[3] + w.b_head[3]);
+        }
+    }
+    __syncthreads();
+
+    // ---- Linear(126->7)/Linear(42->3) + log-softmax + predict(): wave s finishes sample s ----
+    if (wave < SPB && s0 + wave < n) {
+        const int s = wave;
+        float pl[7], vl[3];
+#pragma unroll
+        for (int a = 0; a < 7; a++) pl[a] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) vl[k] = 0.f;
+        for (int j = lane; j < 126; j += 64) {  // nn.Flatten of NCHW: index c*42 + h*7 + w
+            const int c = j / NPOS, q = j % NPOS;
+            const float xv = hb[c * 128 + s * NPOS + q];
+#pragma unroll
+            for (int a = 0; a < 7; a++) pl[a] += xv * w.plin_w[a * 126 + j];
+        }
+        if (lane < NPOS) {
+            const float xv = hb[3 * 128 + s * NPOS + lane];
+#pragma unroll
+            for (int k = 0; k < 3; k++) vl[k] += xv * w.vlin_w[k * NPOS + lane];
+        }
+#pragma unroll
+        for (int a = 0; a < 7; a++) pl[a] = wave_sum(pl[a]) + w.plin_b[a];
+#pragma unroll
+        for (int k = 0; k < 3; k++) vl[k] = wave_sum(vl[k]) + w.vlin_b[k];
+        if (lane == 0) {
+            const i64 slot = s_slot[s];
+            float mx = pl[0];
+#pragma unroll
+            for (int a = 1; a < 7; a++) mx = fmaxf(mx, pl[a]);
+            float se = 0.f;
+#pragma unroll
+            for (int a = 0; a < 7; a++) se += expf(pl[a] - mx);
+            const float lse = logf(se);
+            float mv = fmaxf(vl[0], fmaxf(vl[1], vl[2]));
+            const float sv = expf(vl[0] - mv) + expf(vl[1] - mv) + expf(vl[2] - mv);
+            const float lsv = logf(sv);
+            float vp[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float lv = vl[k] - mv - lsv;
+                if (logv) logv[slot * 3 + k] = lv;
+                vp[k] = expf(lv);
+            }
+#pragma unroll
+            for (int a = 0; a < 7; a++) {
+                const float lp = pl[a] - mx - lse;
+                if (logp) logp[slot * 7 + a] = lp;
+                if (probs) probs[slot * 7 + a] = expf(lp);
+            }
+            // Network.py:83-84: classes [draw, mover wins, mover loses]
+            if (value) value[slot] = (-s_player[s]) * 0.5f * vp[0] + vp[1] - vp[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct BlobReader {
+    const float* p;
+    const float* take(size_t n) {
+        const float* r = p;
+        p += n;
+        return r;
+    }
+};
+struct Bn {
+    const float *g, *b, *m, *v;
+};
+static Bn take_bn(BlobReader& br, size_t c) {
+    Bn bn;
+    bn.g = br.take(c);
+    bn.b = br.take(c);
+    bn.m = br.take(c);
+    bn.v = br.take(c);
+    return bn;
+}
+static inline float bn_scale(const Bn& bn, int c) { return bn.g[c] / sqrtf(bn.v[c] + BN_EPS); }
+static inline float bn_bias(const Bn& bn, int c) { return bn.b[c] - bn.m[c] * bn_scale(bn, c); }
+static inline int co_of_h(int mt, int r, int h) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <class T>
+static int upload(Cnn* c, const std::vector<T>& v, const T** out) {
+    void* q = nullptr;
+    AZ_HIP(hipMalloc(&q, v.size() * sizeof(T) + 64));
+    c->allocs.push_back(q);
+    AZ_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)q;
+    return AZ_OK;
+}
+
+// 3x3 conv weights OIHW (co, ci, 3, 3) with BN scale folded -> per-lane A operand stream [k-pair][lane] float4.
+// k = tap * cin_pad + ci  (cin_pad = 128, or 4 for the stem whose 4th input plane is zero).
+static void pack_conv3(const float* wt, const Bn& bn, int cin, int cin_pad, std::vector<float4>& out) {
+    const int nk = 9 * cin_pad;
+    out.assign((size_t)(nk / 2) * 64, make_float4(0, 0, 0, 0));
+    for (int kp = 0; kp < nk / 2; kp++)
+        for (int lane = 0; lane < 64; lane++) {
+            int k = 2 * kp + (lane >> 5), tap = k / cin_pad, ci = k % cin_pad;
+            float v[4] = {0, 0, 0, 0};
+            if (ci < cin)
+                for (int mt = 0; mt < 4; mt++) {
+                    int co = mt * 32 + (lane & 31);
+                    v[mt] = wt[((size_t)co * cin + ci) * 9 + tap] * bn_scale(bn, co);
+                }
+            out[(size_t)kp * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+}
+// 1x1 conv weights (co, ci) with BN scale folded, reduction index ordered like an accumulator tile (see conv1()).
+static void pack_conv1(const float* wt, const Bn& bn, std::vector<float4>& out) {
+    out.assign((size_t)64 * 64, make_float4(0, 0, 0, 0));
+    for (int mts = 0; mts < 4; mts++)
+        for (int r = 0; r < 16; r++)
+            for (int lane = 0; lane < 64; lane++) {
+                int k = co_of_h(mts, r, lane >> 5);
+                float v[4];
+                for (int mt = 0; mt < 4; mt++) {
+                    int co = mt * 32 + (lane & 31);
+                    v[mt] = wt[(size_t)co * HD + k] * bn_scale(bn, co);
+                }
+                out[(size_t)(mts * 16 + r) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+}
+
+int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out) {
+    if (!blob || n_floats != 500106) {
+        set_error("az_net_load: expected 500106 float32 values (the reference CNN state_dict, see include/azamd.h)");
+        return AZ_ERR_ARG;
+    }
+    Cnn* c = new Cnn();
+    memset(&c->d, 0, sizeof(c->d));
+    BlobReader br{blob};
+    int rc = AZ_OK;
+    std::vector<float4> v4;
+    std::vector<float> vf;
+    // hidden.0 / hidden.1
+    const float* w = br.take(128 * 3 * 9);
+    Bn bn = take_bn(br, 128);
+    pack_conv3(w, bn, 3, 4, v4);
+    if (rc == AZ_OK) rc = upload(c, v4, &c->d.w_stem);
+    vf.resize(128);
+    for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+    if (rc == AZ_OK) rc = upload(c, vf, &c->d.b_stem);
+    for (int b = 0; b < 3; b++) {  // hidden.4/5/6
+        w = br.take((size_t)128 * 128 * 9);
+        bn = take_bn(br, 128);
+        pack_conv3(w, bn, 128, 128, v4);
+        if (rc == AZ_OK) rc = upload(c, v4, &c->d.w3[b]);
+        for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+        if (rc == AZ_OK) rc = upload(c, vf, &c->d.b3[b]);
+        w = br.take((size_t)128 * 128);
+        bn = take_bn(br, 128);
+        pack_conv1(w, bn, v4);
+        if (rc == AZ_OK) rc = upload(c, v4, &c->d.w1[b]);
+        for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+        if (rc == AZ_OK) rc = upload(c, vf, &c->d.b1[b]);
+    }
+    // heads
+    const float* pconv = br.take(3 * 128);
+    Bn pbn = take_bn(br, 3);
+    const float* plw = br.take(7 * 126);
+    const float* plb = br.take(7);
+    const float* vconv = br.take(128);
+    Bn vbn = take_bn(br, 1);
+    const float* vlw = br.take(3 * 42);
+    const float* vlb = br.take(3);
+    std::vector<float> wh((size_t)64 * 64, 0.f);
+    for (int mts = 0; mts < 4; mts++)
+        for (int r = 0; r < 16; r++)
+            for (int lane = 0; lane < 64; lane++) {
+                int k = co_of_h(mts, r, lane >> 5), row = lane & 31;
+                float v = 0.f;
+                if (row < 3) v = pconv[row * 128 + k] * bn_scale(pbn, row);
+                else if (row == 3) v = vconv[k] * bn_scale(vbn, 0);
+                wh[(size_t)(mts * 16 + r) * 64 + lane] = v;
+            }
+    if (rc == AZ_OK) rc = upload(c, wh, &c->d.w_head);
+    std::vector<float> bh = {bn_bias(pbn, 0), bn_bias(pbn, 1), bn_bias(pbn, 2), bn_bias(vbn, 0)};
+    if (rc == AZ_OK) rc = upload(c, bh, &c->d.b_head);
+    if (rc == AZ_OK) rc = upload(c, std::vector<float>(plw, plw + 7 * 126), &c->d.plin_w);
+    if (rc == AZ_OK) rc = upload(c, std::vector<float>(plb, plb + 7), &c->d.plin_b);
+    if (rc == AZ_OK) rc = upload(c, std::vector<float>(vlw, vlw + 3 * 42), &c->d.vlin_w);
+    if (rc == AZ_OK) rc = upload(c, std::vector<float>(vlb, vlb + 3), &c->d.vlin_b);
+    if (rc != AZ_OK) {
+        cnn_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return AZ_OK;
+}
+
+void cnn_destroy(Cnn* c) {
+    if (!c) return;
+    for (void* q : c->allocs) (void)hipFree(q);
+    delete c;
+}
+
+int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, float* probs, float* value,
+                hipStream_t st) {
+    if (n <= 0) return AZ_OK;
+    const unsigned grid = (unsigned)((n + SPB - 1) / SPB);
+    k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, n, nullptr, nullptr, states_dev, logp, logv, probs, value);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
+    const unsigned grid = (unsigned)((d.G + SPB - 1) / SPB);
+    k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
+                                                    d.eval_probs, d.eval_value);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+}  // namespace az
