@@ -57,6 +57,8 @@ SIGNATURES = {
     "az_engine_sync": (C.c_int, [_vp]),
     "az_get_stats": (C.c_int, [_vp, _P(az_stats)]),
     "az_reset_stats": (C.c_int, [_vp]),
+    "az_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "az_get_profile": (C.c_int, [_vp, _vp, _vp]),
     "az_set_noise": (C.c_int, [_vp, _dbl]),
     "az_set_n_playout": (C.c_int, [_vp, _i32]),
     "az_reset_games": (C.c_int, [_vp]),

@@ -97,6 +97,13 @@ struct az_engine {
     Cnn* net = nullptr;
     unsigned long long target = 0;
     int recording = 0;
+    // live kernel timing with HIP events on the engine stream (az_set_profiling / az_get_profile)
+    int prof_on = 0;
+    std::vector<hipEvent_t> prof_ev;   // pairs: [2i] start, [2i+1] stop
+    std::vector<int> prof_cat;
+    size_t prof_used = 0;
+    double prof_ms[4] = {0, 0, 0, 0};
+    long long prof_n[4] = {0, 0, 0, 0};
 
     template <class T>
     int dalloc(T** p, size_t n) {
@@ -111,6 +118,37 @@ struct az_engine {
         return AZ_OK;
     }
 };
+
+enum { PROF_CNN = 0, PROF_SELECT = 1, PROF_BACKUP = 2, PROF_FUSED = 3 };
+
+static int prof_harvest(az_engine* e) {
+    if (e->prof_used == 0) return AZ_OK;
+    AZ_HIP(hipEventSynchronize(e->prof_ev[2 * e->prof_used - 1]));
+    for (size_t i = 0; i < e->prof_used; i++) {
+        float ms = 0.f;
+        AZ_HIP(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+        e->prof_ms[e->prof_cat[i]] += ms;
+        e->prof_n[e->prof_cat[i]] += 1;
+    }
+    e->prof_used = 0;
+    return AZ_OK;
+}
+static int prof_begin(az_engine* e, int cat) {
+    if (!e->prof_on) return AZ_OK;
+    if (e->prof_used * 2 >= e->prof_ev.size()) {
+        int rc = prof_harvest(e);
+        if (rc != AZ_OK) return rc;
+    }
+    e->prof_cat[e->prof_used] = cat;
+    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used], e->stream));
+    return AZ_OK;
+}
+static int prof_end(az_engine* e) {
+    if (!e->prof_on) return AZ_OK;
+    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used + 1], e->stream));
+    e->prof_used++;
+    return AZ_OK;
+}
 
 #define AZ_TRY(x)                 \
     do {                          \
@@ -437,6 +475,7 @@ void az_engine_destroy(az_engine* e) {
         (void)hipStreamDestroy(e->stream);
     }
     if (e->net) cnn_destroy(e->net);
+    for (auto& ev : e->prof_ev) (void)hipEventDestroy(ev);
     for (void* q : e->allocs) (void)hipFree(q);
     if (e->flip_bits) (void)hipFree(e->flip_bits);
     delete e;
@@ -476,6 +515,35 @@ int az_get_stats(az_engine* e, az_stats* out) {
     out->nodes_used = used;
     out->games_finished = (i64)st[ST_GAMES];
     out->plies = (i64)st[ST_PLIES];
+    return AZ_OK;
+}
+
+int az_set_profiling(az_engine* e, int on) {
+    AZ_CHECK_E(e);
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    AZ_TRY(prof_harvest(e));
+    if (on && e->prof_ev.empty()) {
+        const size_t pairs = 4096;
+        e->prof_ev.resize(2 * pairs);
+        e->prof_cat.resize(pairs);
+        for (auto& ev : e->prof_ev) AZ_HIP(hipEventCreate(&ev));
+    }
+    e->prof_on = on ? 1 : 0;
+    for (int i = 0; i < 4; i++) {
+        e->prof_ms[i] = 0;
+        e->prof_n[i] = 0;
+    }
+    return AZ_OK;
+}
+
+int az_get_profile(az_engine* e, double* ms /*[4]*/, int64_t* launches /*[4]*/) {
+    AZ_CHECK_E(e);
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    AZ_TRY(prof_harvest(e));
+    for (int i = 0; i < 4; i++) {
+        if (ms) ms[i] = e->prof_ms[i];
+        if (launches) launches[i] = e->prof_n[i];
+    }
     return AZ_OK;
 }
 
@@ -554,16 +622,26 @@ int az_search(az_engine* e, int32_t n_sims) {
         set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
         return AZ_ERR_STATE;
     }
-    if (d.evaluator == AZ_EVAL_UNIFORM || d.evaluator == AZ_EVAL_HASH) return launch_search_fused(d, n_sims, e->stream);
+    if (d.evaluator == AZ_EVAL_UNIFORM || d.evaluator == AZ_EVAL_HASH) {
+        AZ_TRY(prof_begin(e, PROF_FUSED));
+        AZ_TRY(launch_search_fused(d, n_sims, e->stream));
+        return prof_end(e);
+    }
     if (d.evaluator == AZ_EVAL_CNN) {
         if (!e->net) {
             set_error("AZ_EVAL_CNN: call az_net_load first");
             return AZ_ERR_NO_NET;
         }
         for (int s = 0; s < n_sims; s++) {
+            AZ_TRY(prof_begin(e, PROF_SELECT));
             AZ_TRY(launch_select(d, e->stream));
+            AZ_TRY(prof_end(e));
+            AZ_TRY(prof_begin(e, PROF_CNN));
             AZ_TRY(cnn_eval_leaves(e->net, d, e->stream));
+            AZ_TRY(prof_end(e));
+            AZ_TRY(prof_begin(e, PROF_BACKUP));
             AZ_TRY(launch_backup(d, e->stream));
+            AZ_TRY(prof_end(e));
         }
         return AZ_OK;
     }

@@ -175,6 +175,16 @@ class SelfPlayEngine:
         check(self.L.az_get_stats(self.h, C.byref(st)))
         return {n: getattr(st, n) for n, _ in st._fields_}
 
+    def set_profiling(self, on=True):
+        check(self.L.az_set_profiling(self.h, 1 if on else 0))
+
+    def get_profile(self):
+        ms = np.zeros(4, np.float64)
+        n = np.zeros(4, np.int64)
+        check(self.L.az_get_profile(self.h, ptr(ms), ptr(n)))
+        names = ("cnn", "select", "backup", "fused")
+        return {k: dict(ms=float(ms[i]), launches=int(n[i])) for i, k in enumerate(names)}
+
     def reset_stats(self):
         check(self.L.az_reset_stats(self.h))
 

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- the self-play hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on, per GPU): Connect4 self-play,
+2048 concurrent games, 500 playouts per move, the reference's real CNN checkpoint evaluated on whole leaf batches
+by the fused fp32-MFMA kernel, Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for
+10 plies then 1e-3, tree reuse, finished slots refilled with fresh games (Connect4/config.py:1-14).
+A "step" = one lockstep ply of every game slot: 500 x (select -> CNN leaf batch -> expand/backup), then move
+selection, env step, trajectory record, refill; finished trajectories are packed, all-gathered over RCCL (N>1) and
+expanded into ReplayBuffer-shaped tensors inside the timed region.
+
+value (games/s) = slot-plies per second / mean plies per finished game (steady-state estimator; the raw number of
+games that finished inside the timed window is reported as config.games_finished_in_window).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_LEAF = 41.62e6          # MAC = 2 flops, stem + 3 blocks + heads
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
+
+
+def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0):
+    """The CPU oracle (C port of the reference algorithm: sequential single-game MCTS, one batch-1 fp32 CNN forward
+    per playout) timed on this box's host, one thread, on a bounded sample: whole moves of one game until the
+    budget is used."""
+    from oracle import oracle as orc
+    net = orc.CNN(blob)
+    t = orc.MCTS("Connect4", c_init=1.25, n_playout=n_playout, eval_kind=orc.EVAL_CNN, net=net)
+    env = orc.Env("Connect4")
+    t0 = time.perf_counter()
+    moves = 0
+    rng = np.random.default_rng(0)
+    ply = games = 0
+    while time.perf_counter() - t0 < budget_s:
+        if env.done():  # next game of the sample
+            env = orc.Env("Connect4")
+            t.reset()
+            ply = 0
+            games += 1
+        acts, vis = t.get_action_visits(env)
+        # sample the move from the visit distribution for the first 10 plies like the GPU workload (temp 1.0)
+        p = np.asarray(vis, dtype=np.float64)
+        a = acts[int(rng.choice(len(acts), p=p / p.sum()))] if ply < 10 else acts[int(np.argmax(vis))]
+        t.prune_root(a)
+        env.step(a)
+        moves += 1
+        ply += 1
+    dt = time.perf_counter() - t0
+    sims = t.stat_playouts
+    sims_s = sims / dt
+    return dict(value=sims_s / (n_playout * mean_len), unit="games/s", cores=1, kind="port",
+                sims_per_s=sims_s, sample="%d moves x %d playouts over %d Connect4 self-play game(s) (%.1f s), oracle/az_oracle*.c, "
+                "1 thread, no Dirichlet/flips; games/s = sims/s / (%d * %.1f plies)"
+                % (moves, n_playout, games + 1, dt, n_playout, mean_len))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=2048, help="concurrent game slots per GPU")
+    ap.add_argument("--playouts", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cohort", type=int, default=512, help="games of the untimed cohort that measures plies/game")
+    ap.add_argument("--mean-plies", type=float, default=0.0, help="use this plies/game instead of playing a cohort")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from alphazero_amd.collector import ReplaySink, TrajectoryGatherer
+    from alphazero_amd.engine import SelfPlayEngine
+
+    G, S = args.games, args.playouts
+    blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
+    eng = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
+                         reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
+                         game_id_base=rank * (1 << 40))
+    eng.load_net(blob)
+    gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
+    sink = ReplaySink("Connect4", capacity=1 << 20, device=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    def one_step():
+        eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
+        eng.sync()
+        recs = gather.gather()          # pack on device -> all_gather (RCCL) -> records of every rank
+        sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
+
+    for _ in range(args.warmup):
+        one_step()
+    eng.reset_stats()
+    eng.set_profiling(True)
+    g0, _ = eng.traj_count()
+    stored0 = sink.total_stored
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.get_profile()
+    st = eng.stats()
+    eng.set_profiling(False)
+
+    # aggregate over ranks: MAX time, SUM of work
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    work = torch.tensor([st["plies"], st["playouts"], st["games_finished"], st["leaf_evals"], st["levels"],
+                         st["terminal_hits"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    dt_all = float(tmax.item())
+    plies, playouts, finished, evals, levels, term = [float(x) for x in work.tolist()]
+
+    # mean plies per game, untimed and unbiased: one complete cohort (every game started at a reset is played to its
+    # end, no refill), so short games are not over-represented the way they are among the first finishers.
+    if args.mean_plies > 0:  # profiling runs: skip the cohort so that every CNN launch in the trace is a full batch
+        mean_len = args.mean_plies
+    else:
+        cohort = min(G, args.cohort)
+        eng.traj_fetch(clear=True)
+        n_done = eng.selfplay(cohort, temp=1.0, first_n_steps=10)
+        cg, cp = eng.traj_count()
+        assert cg == n_done == cohort, (cg, n_done, cohort)
+        mean_len = cp / cg
+
+    if rank == 0:
+        games_s = (plies / dt_all) / mean_len
+        cnn = prof["cnn"]
+        cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
+        leaves_per_launch = (evals / world) / max(cnn["launches"], 1)
+        achieved = FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12
+        depth = levels / max(playouts, 1)
+        out = {
+            "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_all / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "sims_per_sec": playouts / dt_all,
+            "config": {"workload": "Connect4 CNN self-play, %d concurrent games/GPU x %d playouts/move, real "
+                                   "AZ_Connect4_CNN_current weights, Dirichlet 0.7, random flips, tree reuse "
+                                   "(BASELINE configs[2]%s)" % (G, S, "; trajectories all-gathered over RCCL into "
+                                                                "ReplayBuffer tensors" if world > 1 else ""),
+                       "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
+                       "games_finished_in_window": finished, "slot_plies_in_window": plies,
+                       "leaf_evals": evals, "terminal_hits": term, "mean_tree_depth": depth,
+                       "plies_stored_in_replay": sink.total_stored - stored0,
+                       "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
+            "roofline": {"bound": "mfma", "kernel": "k_cnn_forward", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
+                         "launches": cnn["launches"]},
+            "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, S, mean_len, args.cpu_budget)
+            out["config"]["x_cpu_port_1core"] = games_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,11 @@ void az_engine_destroy(az_engine *e);
 int az_engine_sync(az_engine *e);                    /* hipStreamSynchronize on the engine stream         */
 int az_get_stats(az_engine *e, az_stats *out);
 int az_reset_stats(az_engine *e);
+/* Live kernel timing with HIP events recorded on the engine's own stream around every search kernel launch.
+ * Categories: 0 = CNN leaf evaluation (K3), 1 = select (K2), 2 = expand/backup (K2), 3 = fused search (K2).
+ * az_get_profile returns accumulated milliseconds and launch counts since az_set_profiling(e, 1). */
+int az_set_profiling(az_engine *e, int on);
+int az_get_profile(az_engine *e, double *ms4, int64_t *launches4);
 /* MCTS.train()/eval() (MCTS.py:100-106) + alpha: switch Dirichlet noise for FUTURE expansions. */
 int az_set_noise(az_engine *e, double dirichlet_alpha);
 int az_set_n_playout(az_engine *e, int32_t n_playout);

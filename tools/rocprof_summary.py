@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) result into the text summaries kept under profiles/.
+
+    python tools/rocprof_summary.py gpurun_out/prof/bench_results.db > profiles/r01_bench_kernel_stats.txt
+    python tools/rocprof_summary.py --pmc gpurun_out/pmc/x_results.db > profiles/r01_pmc_fetch.txt
+
+--kernel-trace --stats runs: per-kernel calls / total / average / min / max duration (from the dispatch table).
+--pmc runs: per-kernel sum and per-dispatch mean of every collected counter.
+"""
+import sqlite3
+import sys
+
+
+def kernel_stats(db):
+    c = sqlite3.connect(db)
+    rows = list(c.execute(
+        "select k.name, count(*), sum(k.end - k.start), avg(k.end - k.start), min(k.end - k.start), "
+        "max(k.end - k.start) from kernels k group by k.name order by 3 desc"))
+    total = sum(r[2] for r in rows) or 1
+    print("# rocprofv3 --kernel-trace --stats   (durations in microseconds)")
+    print("%-70s %9s %14s %11s %11s %11s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    for name, n, tot, avg, mn, mx in rows:
+        short = name.split("(")[0][-70:]
+        print("%-70s %9d %14.1f %11.2f %11.2f %11.2f %6.2f%%" % (short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3,
+                                                              100.0 * tot / total))
+
+
+def pmc_stats(db):
+    c = sqlite3.connect(db)
+    cols = [d[0] for d in c.execute("select * from counters_collection limit 1").description]
+    print("# rocprofv3 --pmc   columns available:", ", ".join(cols))
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    rows = list(c.execute(
+        "select %s, counter_name, count(*), sum(value), avg(value) from counters_collection group by 1, 2 order by 1, 2"
+        % namecol))
+    print("%-60s %-28s %9s %20s %18s" % ("kernel", "counter", "dispatches", "sum", "mean/dispatch"))
+    for name, ctr, n, s, a in rows:
+        print("%-60s %-28s %9d %20.1f %18.1f" % (name.split("(")[0][-60:], ctr, n, s, a))
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--pmc" in sys.argv:
+        pmc_stats(args[0])
+    else:
+        kernel_stats(args[0])
