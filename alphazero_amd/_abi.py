@@ -96,6 +96,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AzError("libazamd.so is missing (%s): build it with `make -C alphazero_amd/csrc`; "
                       "there is no CPU fallback" % LIB_PATH)
+    try:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; loading it FIRST makes libazamd bind
+        # to that same runtime, so torch tensors' device pointers (collector.py) are valid inside our kernels.
+        # (Loaded the other way round, torch's runtime finds no GPU.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)

@@ -568,9 +568,34 @@ int az_set_n_playout(az_engine* e, int32_t n) {
     return AZ_OK;
 }
 
+// Grow the committed-trajectory arrays to hold `need` plies (only while they are empty).
+static int ensure_out_cap(az_engine* e, i64 need) {
+    Play& p = e->p;
+    if (need <= p.out_cap) return AZ_OK;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    unsigned long long cnt = 0;
+    AZ_HIP(hipMemcpy(&cnt, p.out_count, 8, hipMemcpyDeviceToHost));
+    if (cnt != 0) {
+        set_error("trajectory buffer not empty: az_traj_fetch(clear) before asking for more games");
+        return AZ_ERR_STATE;
+    }
+    const GameInfo& gi = e->gi;
+    int rc = AZ_OK;
+    rc = e->dalloc(&p.out_state, (size_t)need * gi.W);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_pi, (size_t)need * gi.A);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_z, (size_t)need);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_player, (size_t)need);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_action, (size_t)need);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_done, (size_t)need);
+    if (rc == AZ_OK) rc = e->dalloc(&p.out_gid, (size_t)need);
+    if (rc == AZ_OK) p.out_cap = need;  // the smaller old arrays stay owned by the engine until it is destroyed
+    return rc;
+}
+
 int az_reset_games(az_engine* e) {
     AZ_CHECK_E(e);
     const Dev& d = e->d;
+    AZ_HIP(hipMemsetAsync(d.err, 0, sizeof(u32), e->stream));
     AZ_HIP(hipMemsetAsync(d.root_state, 0, (size_t)d.G * d.W * sizeof(u64), e->stream));
     AZ_TRY(launch_init_slots(d, e->cfg.game == AZ_GAME_NBTTT ? 1 : 0, e->cfg.game_id_base, e->stream));
     unsigned long long g = (unsigned long long)d.G;
@@ -743,6 +768,10 @@ int64_t az_selfplay(az_engine* e, int64_t n_games_target, double temp, int32_t f
     AZ_CHECK_E(e);
     if (n_games_target <= 0) return AZ_ERR_ARG;
     AZ_TRY(az_reset_games(e));
+    unsigned long long zero = 0;
+    AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(e->p.out_games, &zero, 8, hipMemcpyHostToDevice));
+    AZ_TRY(ensure_out_cap(e, (n_games_target + e->d.G) * (i64)e->gi.MAX_PLIES));
     e->target = (unsigned long long)n_games_target;
     const Dev& d = e->d;
     if (n_games_target < d.G) {  // fewer games than slots: park the surplus slots
@@ -750,9 +779,6 @@ int64_t az_selfplay(az_engine* e, int64_t n_games_target, double temp, int32_t f
         for (i64 g = 0; g < n_games_target; g++) act[g] = 1;
         AZ_HIP(hipMemcpy(d.active, act.data(), d.G, hipMemcpyHostToDevice));
     }
-    unsigned long long zero = 0;
-    AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
-    AZ_HIP(hipMemcpy(e->p.out_games, &zero, 8, hipMemcpyHostToDevice));
     unsigned long long finished = 0;
     for (int64_t step = 0; max_steps <= 0 || step < max_steps; step++) {
         AZ_TRY(az_selfplay_step(e, temp, first_n_steps, 1));

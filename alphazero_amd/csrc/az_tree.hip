@@ -48,7 +48,11 @@ __device__ inline typename G::State load_root_state(const Dev& d, int g) {
     return s;
 }
 
-// Synthetic evaluators (see oracle/az_oracle.c orc_eval_hash for the specification).
+// Synthetic evaluators standing in for CNN.predict (Network.py:78-85) in tree-only runs.
+//   UNIFORM: probs = f32(1/A) for every action, value 0 (BASELINE config 2).
+//   HASH   : h = fold of splitmix64 over the packed words of the EVALUATED position; raw_a = ((mix(h+a+1) >> 40) + 1) / 2^24,
+//            probs = raw / left-to-right f32 sum(raw), value = (mix(h+64) >> 40) / 2^23 - 1.  Specified in DESIGN.md so that any
+//            implementation (the reference through a fake policy_value_fn, a CPU checker, this kernel) computes identical bits.
 template <class G>
 __device__ inline void eval_synthetic(int kind, u64 seed, const typename G::State& aug, float* probs, float& value) {
     if (kind == AZ_EVAL_UNIFORM) {
