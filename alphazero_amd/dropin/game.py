@@ -1,0 +1,88 @@
+"""Game loop with the reference's interface (game.py:8-58) plus its batched sibling.
+
+start_play / start_self_play drive ONE game through player.get_action exactly like the reference (so play.py and
+Pipeline.data_collector run unchanged).  start_self_play_batch plays many games in lockstep on the device
+(az_selfplay) and yields the same 6-tuples per game."""
+import numpy as np
+
+
+class Game:
+    def __init__(self, env):
+        self.env = env
+
+    def start_play(self, player1, player2, show=1):
+        self.env.reset()
+        if show:
+            self.env.show()
+        while True:
+            player = player1 if self.env.turn == 1 else player2
+            action, probs, *_ = player.get_action(self.env)
+            player.reset_player()
+            self.env.step(action)
+            if show:
+                self.env.show()
+            if self.env.done():
+                winner = self.env.winPlayer()
+                if show:
+                    print("Game end. Winner is %s" % ("X" if winner == 1 else "O") if winner != 0 else "Game end. Draw")
+                return winner
+
+    def start_self_play(self, player, temp=1, first_n_steps=5):
+        self.env.reset()
+        states, mcts_probs, current_players, next_states = [], [], [], []
+        steps = 0
+        while True:
+            temperature = 1e-3 if steps >= first_n_steps else temp
+            action, probs = player.get_action(self.env, temperature)
+            steps += 1
+            states.append(self.env.current_state())
+            mcts_probs.append(probs)
+            current_players.append(self.env.turn)
+            self.env.step(action)
+            next_states.append(self.env.current_state())
+            if self.env.done():
+                winner = self.env.winPlayer()
+                cp = np.array(current_players)
+                winner_z = np.zeros(len(cp))
+                if winner != 0:
+                    winner_z[cp == winner] = 1
+                    winner_z[cp != winner] = -1
+                dones = [False] * len(cp)
+                dones[-1] = True
+                return winner, zip(states, mcts_probs, winner_z, winner_z, next_states, dones)
+
+    def start_self_play_batch(self, player, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
+        """n_games self-play games in lockstep on the device with player's search settings (c_puct, n_playout, alpha,
+        train/eval mode) and network.  Returns a list of (winner, [6-tuples]) in completion order, each 6-tuple as
+        game.py:58 builds it: (state (1,C,H,W) f32, pi (A,) f32, z, z, next_state, done)."""
+        from alphazero_amd.engine import SelfPlayEngine, env_planes_batch, env_step_batch
+        m = player.mcts
+        game = self.env.GAME
+        on_device = hasattr(m.policy, "export_flat")
+        if not on_device:
+            raise NotImplementedError("batched self-play needs the device evaluator (the drop-in CNN)")
+        G = int(n_slots or min(n_games, 2048))
+        eng = SelfPlayEngine(game, n_games=G, n_playout=m.n_playout, c_puct=m.c_init, evaluator="cnn", flip="random",
+                             reuse_tree=bool(player.is_selfplay), dirichlet_alpha=None if m.deterministic else m.alpha,
+                             rng_seed=rng_seed, move="sample", device=getattr(m.policy, "device_index", 0))
+        try:
+            eng.load_net(m.policy.export_flat())
+            eng.selfplay(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
+            t = eng.traj_fetch(clear=True)
+        finally:
+            eng.close()
+        planes = env_planes_batch(game, t["states"])
+        nxt = env_step_batch(game, t["states"], t["action"].astype(np.int32))
+        next_planes = env_planes_batch(game, nxt["states"])
+        out, lo = [], 0
+        ends = np.flatnonzero(t["done"])
+        for hi in ends:
+            hi = int(hi) + 1
+            mover_last = int(t["player"][hi - 1])
+            z_last = float(t["z"][hi - 1])
+            winner = 0 if z_last == 0 else (mover_last if z_last > 0 else -mover_last)
+            tuples = [(planes[i:i + 1], t["pi"][i], float(t["z"][i]), float(t["z"][i]), next_planes[i:i + 1],
+                       bool(t["done"][i])) for i in range(lo, hi)]
+            out.append((winner, tuples))
+            lo = hi
+        return out
