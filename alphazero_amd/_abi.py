@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libazamd.so")
+LIB_PATH = os.environ.get("AZAMD_LIB") or os.path.join(HERE, "libazamd.so")  # AZAMD_LIB: diagnostic builds
 
 GAME_C4, GAME_TTT, GAME_NBTTT = 0, 1, 2
 EVAL_UNIFORM, EVAL_HASH, EVAL_CNN, EVAL_HOST = 0, 1, 2, 3
@@ -28,7 +28,7 @@ class az_config(C.Structure):
         ("c_init", C.c_double), ("c_base", C.c_int32), ("evaluator", C.c_int32), ("eval_seed", C.c_uint64),
         ("flip_mode", C.c_int32), ("reuse_tree", C.c_int32), ("dirichlet_alpha", C.c_double),
         ("rng_seed", C.c_uint64), ("move_mode", C.c_int32), ("max_plies", C.c_int32),
-        ("nodes_per_game", C.c_int64), ("game_id_base", C.c_uint64),
+        ("nodes_per_game", C.c_int64), ("game_id_base", C.c_uint64), ("n_cohorts", C.c_int32),
     ]
 
 
@@ -55,10 +55,12 @@ SIGNATURES = {
     "az_engine_create": (C.c_int, [_P(az_config), _P(_vp)]),
     "az_engine_destroy": (None, [_vp]),
     "az_engine_sync": (C.c_int, [_vp]),
+    "az_get_config": (C.c_int, [_vp, _P(az_config)]),
     "az_get_stats": (C.c_int, [_vp, _P(az_stats)]),
     "az_reset_stats": (C.c_int, [_vp]),
     "az_set_profiling": (C.c_int, [_vp, C.c_int]),
     "az_get_profile": (C.c_int, [_vp, _vp, _vp]),
+    "az_get_profile_busy": (C.c_int, [_vp, _vp]),
     "az_set_noise": (C.c_int, [_vp, _dbl]),
     "az_set_n_playout": (C.c_int, [_vp, _i32]),
     "az_reset_games": (C.c_int, [_vp]),

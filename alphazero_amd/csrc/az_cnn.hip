@@ -67,6 +67,49 @@ __device__ inline int co_of(int mt, int r, int h) { return mt * 32 + (r & 3) + 8
 
 // One 3x3 (or stem) convolution for this wave's 32 positions x 128 output channels.
 //   NKP2 = k-pairs per tap (64 for 128 input channels, 2 for the 4-plane stem image)
+// The weight stream is double buffered in two NAMED register sets (bufA / bufB) and the loop body is unrolled over
+// both, so no register copies exist: a copy `cur = nxt` lets the scheduler sink it next to the MFMA that frees `cur`,
+// which turns the prefetch distance into one MFMA group (measured: MFMA pipe 82 % busy, s_waitcnt vmcnt(7) right
+// after the loads).  Here every load is issued one whole block (U k-pairs = 4U MFMAs = 256 U cycles) before its use.
+template <int U>
+__device__ inline void conv3_load(float4 (&buf)[U], const float4* wl, int k0) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#ifdef AZ_K3_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
+        buf[u] = make_float4(1e-3f * (float)k0, 2e-3f, 3e-3f, 4e-3f);
+#else
+        buf[u] = wl[(size_t)(k0 + u) * 64];
+#endif
+    }
+}
+// LDS side of a block: the U activation values (B operands) of k-pairs k0..k0+U-1 for this lane, and the tap's
+// zero-padding predicate folded in.
+template <int NKP2, int U>
+__device__ inline void conv3_ldsb(float (&b)[U], const float* bptr, int k0) {
+    const int tap = k0 / NKP2;           // U divides NKP2: one tap per block of U k-pairs
+    const int dr = tap / 3 - 1, dc = tap % 3 - 1;
+    const float* bp = bptr + dr * 7 + dc + (k0 % NKP2) * 2 * XS;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#ifdef AZ_K3_DBG_NOB   // diagnostic builds only: no LDS operand traffic, results are garbage
+        b[u] = 0.25f + (float)((size_t)bp & 3);
+#else
+        b[u] = bp[u * 2 * XS];
+#endif
+    }
+}
+template <int NKP2, int U>
+__device__ inline void conv3_block(const float4 (&buf)[U], const float (&b)[U], u32 tapmask, int k0, f32x16 (&acc)[4]) {
+    const bool valid = (tapmask >> (k0 / NKP2)) & 1u;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const float bv = valid ? b[u] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].x, bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].y, bv, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].z, bv, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, bv, acc[3], 0, 0, 0);
+    }
+}
 template <int NKP2>
 __device__ inline void conv3(const float4* __restrict__ wA, const float* xs, int lane, int pbase, u32 tapmask,
                              f32x16 (&acc)[4]) {
@@ -75,54 +118,79 @@ __device__ inline void conv3(const float4* __restrict__ wA, const float* xs, int
     const float4* wl = wA + lane;
     constexpr int NK = 9 * NKP2;
     constexpr int U = (NKP2 >= PF) ? PF : NKP2;
-    float4 cur[U], nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = wl[(size_t)u * 64];
-    for (int k0 = 0; k0 < NK; k0 += U) {
-        const bool more = (k0 + U) < NK;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < U; u++) nxt[u] = wl[(size_t)(k0 + U + u) * 64];
-        }
-        const int tap = k0 / NKP2;           // U divides NKP2: one tap per block of U k-pairs
-        const int dr = tap / 3 - 1, dc = tap % 3 - 1;
-        const bool valid = (tapmask >> tap) & 1u;
-        const float* bp = bptr + dr * 7 + dc + (k0 % NKP2) * 2 * XS;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            float b = bp[u * 2 * XS];
-            b = valid ? b : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].x, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].y, b, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].z, b, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].w, b, acc[3], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = nxt[u];
-        }
+    constexpr int NB = NK / U;           // blocks
+    constexpr int LAST = (NB - 1) * U;
+    float4 bufA[U], bufB[U];
+    float bA[U], bB[U];
+    conv3_load<U>(bufA, wl, 0);
+    conv3_ldsb<NKP2, U>(bA, bptr, 0);
+    // Both operand streams (weights from L2, activations from LDS) are fetched one block ahead of their use.
+    // Loads are UNCONDITIONAL (the index is clamped to the last block, which is simply loaded again): a conditional
+    // load makes a control-flow join at which s_waitcnt insertion has to assume the no-load path and drains the queue.
+    // sched_barrier(0): nothing may be scheduled across -- keeps each load group AHEAD of the block it overlaps
+    // (without it the scheduler sinks the loads below the block to shorten live ranges).
+#pragma unroll 1
+    for (int blk = 0; blk + 1 < NB; blk += 2) {
+        conv3_load<U>(bufB, wl, (blk + 1) * U);
+        conv3_ldsb<NKP2, U>(bB, bptr, (blk + 1) * U);
+        __builtin_amdgcn_sched_barrier(0);
+        conv3_block<NKP2, U>(bufA, bA, tapmask, blk * U, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = min((blk + 2) * U, LAST);
+        conv3_load<U>(bufA, wl, k2);
+        conv3_ldsb<NKP2, U>(bA, bptr, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        conv3_block<NKP2, U>(bufB, bB, tapmask, (blk + 1) * U, acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (NB & 1) conv3_block<NKP2, U>(bufA, bA, tapmask, LAST, acc);
 }
 
 // 1x1 convolution whose input is an accumulator-layout tile set held in registers (hin[mt][r]).
 // k-pair (mt, r) covers input channels co_of(mt, r, 0) [lanes 0-31] and co_of(mt, r, 1) [lanes 32-63]: exactly what
 // each lane half already holds, so the register IS the B operand; the host lays the weights out to match.
-__device__ inline void conv1(const float4* __restrict__ wB, const f32x16 (&hin)[4], int lane, f32x16 (&acc)[4]) {
-    const float4* wl = wB + lane;
+// Weights stream in 16 groups of 4 k-pairs through the same two-buffer scheme; group 0 is loaded by the caller
+// (conv1_prefetch) before the SiLU epilogue of the 3x3 convolution so that its latency hides behind that epilogue.
+constexpr int C1U = 4;
+__device__ inline void conv1_prefetch(const float4* __restrict__ wB, int lane, float4 (&buf)[C1U]) {
+    conv3_load<C1U>(buf, wB + lane, 0);
+}
+template <int G>
+__device__ inline void conv1_group(const float4 (&buf)[C1U], const f32x16 (&hin)[4], f32x16 (&acc)[4]) {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        float4 a[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) a[r] = wl[(size_t)(mt * 16 + r) * 64];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float b = hin[mt][r];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b, acc[3], 0, 0, 0);
-        }
+    for (int u = 0; u < C1U; u++) {
+        const float b = hin[(G * C1U) >> 4][((G * C1U) & 15) + u];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].x, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].y, b, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].z, b, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, b, acc[3], 0, 0, 0);
     }
+}
+template <int G>
+__device__ inline void conv1_pair(const float4* wl, float4 (&bufA)[C1U], float4 (&bufB)[C1U], const f32x16 (&hin)[4],
+                                  f32x16 (&acc)[4]) {
+    constexpr int LASTG = 64 / C1U - 1;
+    conv3_load<C1U>(bufB, wl, (G + 1) * C1U);
+    __builtin_amdgcn_sched_barrier(0);
+    conv1_group<G>(bufA, hin, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv3_load<C1U>(bufA, wl, (G + 2 <= LASTG ? G + 2 : LASTG) * C1U);
+    __builtin_amdgcn_sched_barrier(0);
+    conv1_group<G + 1>(bufB, hin, acc);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ inline void conv1(const float4* __restrict__ wB, float4 (&bufA)[C1U], const f32x16 (&hin)[4], int lane,
+                             f32x16 (&acc)[4]) {
+    const float4* wl = wB + lane;
+    float4 bufB[C1U];
+    conv1_pair<0>(wl, bufA, bufB, hin, acc);
+    conv1_pair<2>(wl, bufA, bufB, hin, acc);
+    conv1_pair<4>(wl, bufA, bufB, hin, acc);
+    conv1_pair<6>(wl, bufA, bufB, hin, acc);
+    conv1_pair<8>(wl, bufA, bufB, hin, acc);
+    conv1_pair<10>(wl, bufA, bufB, hin, acc);
+    conv1_pair<12>(wl, bufA, bufB, hin, acc);
+    conv1_pair<14>(wl, bufA, bufB, hin, acc);
 }
 
 __device__ inline float wave_sum(float v) {
@@ -201,6 +269,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_forward(CnnDev w, i64 n_host, co
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x16)(0.f);
         conv3<64>(w.w3[blk], xs, lane, pbase, tapmask, acc);
+        float4 w1buf[C1U];
+        conv1_prefetch(w.w1[blk], lane, w1buf);
         const float* b3 = w.b3[blk];
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -208,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_forward(CnnDev w, i64 n_host, co
             for (int r = 0; r < 16; r++) acc[mt][r] = silu(acc[mt][r] + b3[co_of(mt, r, h)]);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc2[mt] = (f32x16)(0.f);
-        conv1(w.w1[blk], acc, lane, acc2);
+        conv1(w.w1[blk], w1buf, acc, lane, acc2);
         const float* b1 = w.b1[blk];
         __syncthreads();  // every wave has finished READING xs for this block's conv3x3
 #pragma unroll
@@ -445,7 +515,7 @@ int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, 
 }
 
 int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
-    const unsigned grid = (unsigned)((d.G + SPB - 1) / SPB);
+    const unsigned grid = (unsigned)((d.gn + SPB - 1) / SPB);   // the cohort's slots bound its leaf count
     k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
                                                     d.eval_probs, d.eval_value);
     AZ_HIP(hipGetLastError());

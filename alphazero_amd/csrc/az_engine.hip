@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "az_cnn.hpp"
@@ -97,6 +98,11 @@ struct az_engine {
     Cnn* net = nullptr;
     unsigned long long target = 0;
     int recording = 0;
+    // cohorts: the slots are cut into C ranges whose select -> CNN -> backup chains run on their own streams, so one
+    // cohort's tree kernels and the ragged last round of its CNN launch overlap with the other cohort's CNN launch.
+    int C = 1;
+    hipStream_t cstream[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
     // live kernel timing with HIP events on the engine stream (az_set_profiling / az_get_profile)
     int prof_on = 0;
     std::vector<hipEvent_t> prof_ev;   // pairs: [2i] start, [2i+1] stop
@@ -104,6 +110,9 @@ struct az_engine {
     size_t prof_used = 0;
     double prof_ms[4] = {0, 0, 0, 0};
     long long prof_n[4] = {0, 0, 0, 0};
+    hipEvent_t prof_base = nullptr;          // time origin of the busy-interval union
+    double prof_busy[4] = {0, 0, 0, 0};      // per category: time during which at least one launch was executing
+    double prof_last_end[4] = {0, 0, 0, 0};
 
     template <class T>
     int dalloc(T** p, size_t n) {
@@ -123,29 +132,43 @@ enum { PROF_CNN = 0, PROF_SELECT = 1, PROF_BACKUP = 2, PROF_FUSED = 3 };
 
 static int prof_harvest(az_engine* e) {
     if (e->prof_used == 0) return AZ_OK;
-    AZ_HIP(hipEventSynchronize(e->prof_ev[2 * e->prof_used - 1]));
+    for (size_t i = 0; i < e->prof_used; i++) AZ_HIP(hipEventSynchronize(e->prof_ev[2 * i + 1]));
+    std::vector<std::pair<double, double>> iv[4];
     for (size_t i = 0; i < e->prof_used; i++) {
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         AZ_HIP(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
-        e->prof_ms[e->prof_cat[i]] += ms;
-        e->prof_n[e->prof_cat[i]] += 1;
+        AZ_HIP(hipEventElapsedTime(&t0, e->prof_base, e->prof_ev[2 * i]));
+        const int c = e->prof_cat[i];
+        e->prof_ms[c] += ms;
+        e->prof_n[c] += 1;
+        iv[c].push_back({(double)t0, (double)t0 + (double)ms});
+    }
+    for (int c = 0; c < 4; c++) {  // union of the execution intervals (launches of different cohorts overlap)
+        std::sort(iv[c].begin(), iv[c].end());
+        for (auto& x : iv[c]) {
+            double lo = std::max(x.first, e->prof_last_end[c]);
+            if (x.second > lo) {
+                e->prof_busy[c] += x.second - lo;
+                e->prof_last_end[c] = x.second;
+            }
+        }
     }
     e->prof_used = 0;
     return AZ_OK;
 }
-static int prof_begin(az_engine* e, int cat) {
+static int prof_begin(az_engine* e, int cat, hipStream_t st) {
     if (!e->prof_on) return AZ_OK;
     if (e->prof_used * 2 >= e->prof_ev.size()) {
         int rc = prof_harvest(e);
         if (rc != AZ_OK) return rc;
     }
     e->prof_cat[e->prof_used] = cat;
-    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used], e->stream));
+    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used], st));
     return AZ_OK;
 }
-static int prof_end(az_engine* e) {
+static int prof_end(az_engine* e, hipStream_t st) {
     if (!e->prof_on) return AZ_OK;
-    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used + 1], e->stream));
+    AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used + 1], st));
     e->prof_used++;
     return AZ_OK;
 }
@@ -364,6 +387,8 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     memset(&e->p, 0, sizeof(e->p));
     d.game = cfg->game;
     d.G = (i32)G;
+    d.g0 = 0;
+    d.gn = (i32)G;
     d.S = cfg->n_playout;
     d.A = gi.A;
     d.W = gi.W;
@@ -396,7 +421,7 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     A_(d.eval_probs, G * gi.A);
     A_(d.eval_value, G);
     A_(d.eval_list, G);
-    A_(d.eval_count, 4);
+    A_(d.eval_count, 4 * AZ_MAX_COHORTS);
     A_(d.winner, G);
     A_(d.done, G);
     A_(d.ply, G);
@@ -444,15 +469,27 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     d.tab = dtab;
     d.tab_n = tab_n;
     hipError_t he = hipStreamCreate(&e->stream);
+    // cohorts only pay off where an evaluator launch sits between select and backup (AZ_EVAL_CNN)
+    int C = cfg->n_cohorts;
+    if (C <= 0) C = cfg->evaluator != AZ_EVAL_CNN ? 1 : (G >= 768 ? 3 : (G >= 512 ? 2 : 1));  // measured: DESIGN.md 5
+    if (C > AZ_MAX_COHORTS) C = AZ_MAX_COHORTS;
+    if (cfg->evaluator != AZ_EVAL_CNN || C > G) C = 1;
+    e->C = C;
+    e->cfg.n_cohorts = C;
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    for (int c = 1; c < C && he == hipSuccess; c++) {
+        he = hipStreamCreate(&e->cstream[c]);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming);
+    }
     if (he != hipSuccess) {
-        set_error("hipStreamCreate failed");
+        set_error("hipStreamCreate / hipEventCreate failed");
         az_engine_destroy(e);
         return AZ_ERR_HIP;
     }
     (void)hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice);
     (void)hipMemset(d.stats, 0, ST_N * sizeof(unsigned long long));
     (void)hipMemset(d.err, 0, 16);
-    (void)hipMemset(d.eval_count, 0, 16);
+    (void)hipMemset(d.eval_count, 0, 16 * AZ_MAX_COHORTS);
     (void)hipMemset(p.out_count, 0, 8);
     (void)hipMemset(p.out_games, 0, 8);
     (void)hipMemset(p.games_started, 0, 8);
@@ -470,6 +507,15 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
 void az_engine_destroy(az_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
+    for (int c = 0; c < AZ_MAX_COHORTS; c++) {
+        if (e->cstream[c]) {
+            (void)hipStreamSynchronize(e->cstream[c]);
+            (void)hipStreamDestroy(e->cstream[c]);
+        }
+        if (e->ev_join[c]) (void)hipEventDestroy(e->ev_join[c]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->prof_base) (void)hipEventDestroy(e->prof_base);
     if (e->stream) {
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamDestroy(e->stream);
@@ -494,6 +540,14 @@ int az_engine_sync(az_engine* e) {
         set_error("trajectory buffer overflow: fetch trajectories more often");
         return AZ_ERR_ARENA;
     }
+    return AZ_OK;
+}
+
+int az_get_config(az_engine* e, az_config* out) {
+    AZ_CHECK_E(e);
+    if (!out) return AZ_ERR_ARG;
+    *out = e->cfg;
+    out->nodes_per_game = e->d.cap;
     return AZ_OK;
 }
 
@@ -523,7 +577,7 @@ int az_set_profiling(az_engine* e, int on) {
     AZ_HIP(hipStreamSynchronize(e->stream));
     AZ_TRY(prof_harvest(e));
     if (on && e->prof_ev.empty()) {
-        const size_t pairs = 4096;
+        const size_t pairs = 16384;
         e->prof_ev.resize(2 * pairs);
         e->prof_cat.resize(pairs);
         for (auto& ev : e->prof_ev) AZ_HIP(hipEventCreate(&ev));
@@ -532,6 +586,13 @@ int az_set_profiling(az_engine* e, int on) {
     for (int i = 0; i < 4; i++) {
         e->prof_ms[i] = 0;
         e->prof_n[i] = 0;
+        e->prof_busy[i] = 0;
+        e->prof_last_end[i] = 0;
+    }
+    if (on) {
+        if (!e->prof_base) AZ_HIP(hipEventCreate(&e->prof_base));
+        AZ_HIP(hipEventRecord(e->prof_base, e->stream));
+        AZ_HIP(hipStreamSynchronize(e->stream));
     }
     return AZ_OK;
 }
@@ -544,6 +605,15 @@ int az_get_profile(az_engine* e, double* ms /*[4]*/, int64_t* launches /*[4]*/) 
         if (ms) ms[i] = e->prof_ms[i];
         if (launches) launches[i] = e->prof_n[i];
     }
+    return AZ_OK;
+}
+
+int az_get_profile_busy(az_engine* e, double* busy_ms /*[4]*/) {
+    AZ_CHECK_E(e);
+    if (!busy_ms) return AZ_ERR_ARG;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    AZ_TRY(prof_harvest(e));
+    for (int i = 0; i < 4; i++) busy_ms[i] = e->prof_busy[i];
     return AZ_OK;
 }
 
@@ -648,25 +718,51 @@ int az_search(az_engine* e, int32_t n_sims) {
         return AZ_ERR_STATE;
     }
     if (d.evaluator == AZ_EVAL_UNIFORM || d.evaluator == AZ_EVAL_HASH) {
-        AZ_TRY(prof_begin(e, PROF_FUSED));
+        AZ_TRY(prof_begin(e, PROF_FUSED, e->stream));
         AZ_TRY(launch_search_fused(d, n_sims, e->stream));
-        return prof_end(e);
+        return prof_end(e, e->stream);
     }
     if (d.evaluator == AZ_EVAL_CNN) {
         if (!e->net) {
             set_error("AZ_EVAL_CNN: call az_net_load first");
             return AZ_ERR_NO_NET;
         }
+        // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
+        // (disjoint slots, own leaf list and counter) and are issued round-robin onto their own streams.
+        const int C = e->C;
+        Dev dc[AZ_MAX_COHORTS];
+        hipStream_t cs[AZ_MAX_COHORTS];
+        for (int c = 0; c < C; c++) {
+            dc[c] = d;
+            const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
+            dc[c].g0 = (i32)lo;
+            dc[c].gn = (i32)(hi - lo);
+            dc[c].eval_count = d.eval_count + 4 * c;
+            dc[c].eval_list = d.eval_list + lo;
+            cs[c] = c == 0 ? e->stream : e->cstream[c];   // cohort 0 rides on the engine stream (4 hardware queues)
+        }
+        if (C > 1) {  // fork: the cohort streams start after everything queued on the engine stream
+            AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
+            for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
+        }
         for (int s = 0; s < n_sims; s++) {
-            AZ_TRY(prof_begin(e, PROF_SELECT));
-            AZ_TRY(launch_select(d, e->stream));
-            AZ_TRY(prof_end(e));
-            AZ_TRY(prof_begin(e, PROF_CNN));
-            AZ_TRY(cnn_eval_leaves(e->net, d, e->stream));
-            AZ_TRY(prof_end(e));
-            AZ_TRY(prof_begin(e, PROF_BACKUP));
-            AZ_TRY(launch_backup(d, e->stream));
-            AZ_TRY(prof_end(e));
+            for (int c = 0; c < C; c++) {
+                AZ_TRY(prof_begin(e, PROF_SELECT, cs[c]));
+                AZ_TRY(launch_select(dc[c], cs[c], false));
+                AZ_TRY(prof_end(e, cs[c]));
+                AZ_TRY(prof_begin(e, PROF_CNN, cs[c]));
+                AZ_TRY(cnn_eval_leaves(e->net, dc[c], cs[c]));
+                AZ_TRY(prof_end(e, cs[c]));
+                AZ_TRY(prof_begin(e, PROF_BACKUP, cs[c]));
+                AZ_TRY(launch_backup(dc[c], cs[c]));
+                AZ_TRY(prof_end(e, cs[c]));
+            }
+        }
+        if (C > 1) {  // join: later work on the engine stream (move selection, advance) waits for every cohort
+            for (int c = 1; c < C; c++) {
+                AZ_HIP(hipEventRecord(e->ev_join[c], cs[c]));
+                AZ_HIP(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+            }
         }
         return AZ_OK;
     }
@@ -681,7 +777,7 @@ int az_select(az_engine* e, uint64_t* leaf_states, uint8_t* flags) {
         set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
         return AZ_ERR_STATE;
     }
-    AZ_TRY(launch_select(d, e->stream));
+    AZ_TRY(launch_select(d, e->stream, true));
     AZ_HIP(hipStreamSynchronize(e->stream));
     if (leaf_states)
         AZ_HIP(hipMemcpy(leaf_states, d.leaf_state, (size_t)d.G * d.W * sizeof(u64), hipMemcpyDeviceToHost));

@@ -30,6 +30,7 @@ enum StatIdx { ST_PLAYOUTS = 0, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CHILDREN, S
 // Everything a kernel needs, passed by value (all pointers are device memory).
 struct Dev {
     i32 game, G, S, A, W, MAXD;
+    i32 g0, gn;        // slot range [g0, g0+gn) the split-search kernels of THIS launch cover (a cohort; default: all)
     i64 cap;           // nodes per game arena
     uint4* nodes;      // [G][cap]
     u64* root_state;   // [G][W]
@@ -62,8 +63,8 @@ struct Dev {
     u64* leaf_state;      // [G][W] position handed to the evaluator (mirrored when flipped)
     float* eval_probs;    // [G][A]
     float* eval_value;    // [G]
-    u32* eval_list;       // [G] compacted list of slots whose leaf needs the network
-    u32* eval_count;      // [1]
+    u32* eval_list;       // [G] compacted list of slots whose leaf needs the network (a cohort's list starts at g0)
+    u32* eval_count;      // [1] per cohort; k_select counts up, k_backup clears it for the next round
     // status
     i8* winner;           // [G]
     u8* done;             // [G]
@@ -93,7 +94,7 @@ int launch_env_flip(int game, i64 n, const u64* in, u64* out, i8* fa, hipStream_
 int launch_puct(double c_init, i32 c_base, i64 n, const i32* Np, const i32* nv, const float* Q, const float* P,
                 const float2* tab, i32 tab_n, float* score, hipStream_t st);
 int launch_search_fused(const Dev& d, int n_sims, hipStream_t st);
-int launch_select(const Dev& d, hipStream_t st);
+int launch_select(const Dev& d, hipStream_t st, bool clear_count);
 int launch_backup(const Dev& d, hipStream_t st);
 int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,
                          float* rootQ, hipStream_t st);

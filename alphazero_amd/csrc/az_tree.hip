@@ -336,8 +336,8 @@ __global__ __launch_bounds__(256) void k_select(Dev d) {
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ float s_Q[GPB][G::MAXD];
     const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
-    const int g = blockIdx.x * GPB + grp;
-    if (g >= d.G) return;
+    const int g = d.g0 + blockIdx.x * GPB + grp;
+    if (g >= d.g0 + d.gn) return;
     if (!d.active[g]) {
         if (gl == 0) d.leaf_flags[g] = 0u;
         return;
@@ -378,8 +378,10 @@ __global__ __launch_bounds__(256) void k_backup(Dev d) {
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ float s_Q[GPB][G::MAXD];
     const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
-    const int g = blockIdx.x * GPB + grp;
-    if (g >= d.G) return;
+    // the evaluator has consumed this round's compacted leaf list: clear the cohort's counter for the next k_select
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d.eval_count = 0u;
+    const int g = d.g0 + blockIdx.x * GPB + grp;
+    if (g >= d.g0 + d.gn) return;
     const u32 flags = d.leaf_flags[g];
     if (!(flags & 8u)) return;
     uint4* nodes = d.nodes + (i64)g * d.cap;
@@ -490,11 +492,11 @@ int launch_search_fused(const Dev& d, int n_sims, hipStream_t st) {
     return AZ_OK;
 }
 
-int launch_select(const Dev& d, hipStream_t st) {
-    AZ_HIP(hipMemsetAsync(d.eval_count, 0, sizeof(u32), st));
+int launch_select(const Dev& d, hipStream_t st, bool clear_count) {
+    if (clear_count) AZ_HIP(hipMemsetAsync(d.eval_count, 0, sizeof(u32), st));
     AZ_DISPATCH_GAME(game_of(d), {
         int gpb = 256 / GT::LG;
-        k_select<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
+        k_select<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
@@ -503,7 +505,7 @@ int launch_select(const Dev& d, hipStream_t st) {
 int launch_backup(const Dev& d, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
         int gpb = 256 / GT::LG;
-        k_backup<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
+        k_backup<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;

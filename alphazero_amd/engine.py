@@ -20,7 +20,7 @@ MOVES = {"first_max": MOVE_FIRST_MAX, "sample": MOVE_SAMPLE}
 class SelfPlayEngine:
     def __init__(self, game="Connect4", n_games=1, n_playout=500, c_puct=1.25, evaluator="uniform", eval_seed=0,
                  flip="never", reuse_tree=True, dirichlet_alpha=None, rng_seed=0, move="first_max", device=0,
-                 max_plies=0, nodes_per_game=0, game_id_base=0):
+                 max_plies=0, nodes_per_game=0, game_id_base=0, n_cohorts=0):
         _abi.require_gpu()
         self.game = GAME_IDS.get(game, game)
         self.L = lib()
@@ -36,12 +36,15 @@ class SelfPlayEngine:
         cfg.dirichlet_alpha = float(dirichlet_alpha) if dirichlet_alpha else 0.0
         cfg.rng_seed, cfg.move_mode = int(rng_seed), MOVES.get(move, move)
         cfg.max_plies, cfg.nodes_per_game, cfg.game_id_base = int(max_plies), int(nodes_per_game), int(game_id_base)
+        cfg.n_cohorts = int(n_cohorts)
         self.cfg = cfg
         self.n_playout = int(n_playout)
         h = C.c_void_p()
         check(self.L.az_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self._keep = None
+        check(self.L.az_get_config(self.h, C.byref(cfg)))   # resolved values of the 0 = auto fields
+        self.n_cohorts, self.nodes_per_game = int(cfg.n_cohorts), int(cfg.nodes_per_game)
 
     def close(self):
         if getattr(self, "h", None):
@@ -182,8 +185,10 @@ class SelfPlayEngine:
         ms = np.zeros(4, np.float64)
         n = np.zeros(4, np.int64)
         check(self.L.az_get_profile(self.h, ptr(ms), ptr(n)))
+        busy = np.zeros(4, np.float64)
+        check(self.L.az_get_profile_busy(self.h, ptr(busy)))
         names = ("cnn", "select", "backup", "fused")
-        return {k: dict(ms=float(ms[i]), launches=int(n[i])) for i, k in enumerate(names)}
+        return {k: dict(ms=float(ms[i]), launches=int(n[i]), busy_ms=float(busy[i])) for i, k in enumerate(names)}
 
     def reset_stats(self):
         check(self.L.az_reset_stats(self.h))

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--cohort", type=int, default=512, help="games of the untimed cohort that measures plies/game")
     ap.add_argument("--mean-plies", type=float, default=0.0, help="use this plies/game instead of playing a cohort")
+    ap.add_argument("--cohorts", type=int, default=0, help="slot ranges searched on their own HIP streams (0 = engine default)")
     args = ap.parse_args()
 
     import torch
@@ -95,7 +96,7 @@ def main():
     blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
     eng = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                          reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
-                         game_id_base=rank * (1 << 40))
+                         game_id_base=rank * (1 << 40), n_cohorts=args.cohorts)
     eng.load_net(blob)
     gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
     sink = ReplaySink("Connect4", capacity=1 << 20, device=torch.device("cuda", local))
@@ -155,7 +156,11 @@ def main():
         cnn = prof["cnn"]
         cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
         leaves_per_launch = (evals / world) / max(cnn["launches"], 1)
-        achieved = FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12
+        # K3 launches of different cohorts run concurrently on their own streams, so the time the kernel occupies the
+        # GPU is the UNION of the launches' [start, stop] intervals (HIP events on the launch streams), not their sum.
+        # achieved = algorithmic FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the
+        # launches do not overlap, i.e. --cohorts 1).
+        achieved = FLOP_PER_LEAF * (evals / world) / (cnn["busy_ms"] * 1e-3) / 1e12
         depth = levels / max(playouts, 1)
         out = {
             "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
@@ -174,7 +179,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_cnn_forward", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
-                         "launches": cnn["launches"]},
+                         "launches": cnn["launches"], "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"],
+                         "concurrent_cohorts": eng.n_cohorts,
+                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12},
             "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -47,6 +47,8 @@ extern "C" {
 #define AZ_MOVE_FIRST_MAX 0 /* parity: first maximum of the sampling distribution, insertion order       */
 #define AZ_MOVE_SAMPLE 1    /* production: sample (player.py:106-111)                                     */
 
+#define AZ_MAX_COHORTS 4
+
 #define AZ_OK 0
 #define AZ_ERR_ARG (-1)
 #define AZ_ERR_NO_DEVICE (-2)
@@ -76,6 +78,9 @@ typedef struct az_config {
     int32_t max_plies;      /* per-game ply cap for arena sizing; 0 = game maximum                        */
     int64_t nodes_per_game; /* arena capacity in nodes; 0 = 1 + A*S*(reuse ? max_plies : 1)               */
     uint64_t game_id_base;  /* global id of slot 0 (multi-GPU: rank * n_games), keys the RNG streams      */
+    int32_t n_cohorts;      /* AZ_EVAL_CNN: slot ranges searched on their own HIP streams so that one range's  */
+                            /* tree kernels overlap the other's CNN launch; 0 = auto (3 from 768 slots), max 4.   */
+                            /* Results do not depend on it (games are independent).                            */
 } az_config;
 
 typedef struct az_stats {
@@ -116,6 +121,8 @@ int az_env_step_batch_dev(int game, int64_t n, const uint64_t *states_in_dev, co
 int az_engine_create(const az_config *cfg, az_engine **out);
 void az_engine_destroy(az_engine *e);
 int az_engine_sync(az_engine *e);                    /* hipStreamSynchronize on the engine stream         */
+/* the configuration in force, with every 0 = auto field resolved (c_base, nodes_per_game, n_cohorts). */
+int az_get_config(az_engine *e, az_config *out);
 int az_get_stats(az_engine *e, az_stats *out);
 int az_reset_stats(az_engine *e);
 /* Live kernel timing with HIP events recorded on the engine's own stream around every search kernel launch.
@@ -123,6 +130,9 @@ int az_reset_stats(az_engine *e);
  * az_get_profile returns accumulated milliseconds and launch counts since az_set_profiling(e, 1). */
 int az_set_profiling(az_engine *e, int on);
 int az_get_profile(az_engine *e, double *ms4, int64_t *launches4);
+/* per category, the time (ms) during which at least one launch of it was executing: the union of the launches'
+ * [start, stop] intervals.  Equals the sum of durations when launches never overlap (n_cohorts == 1). */
+int az_get_profile_busy(az_engine *e, double *busy_ms4);
 /* MCTS.train()/eval() (MCTS.py:100-106) + alpha: switch Dirichlet noise for FUTURE expansions. */
 int az_set_noise(az_engine *e, double dirichlet_alpha);
 int az_set_n_playout(az_engine *e, int32_t n_playout);

@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# Diagnostic builds of the K3 kernel with one operand stream removed (results are garbage; timing only):
+#   now = no weight loads, nob = no LDS activation loads, nowb = neither.  Output: gpurun_out/dbg/libazamd_<v>.so
+# Usage (build here, run on the GPU box):  AZAMD_LIB=gpurun_out/dbg/libazamd_now.so python tools/k3_sweep.py 768 6144
+set -euo pipefail
+cd "$(dirname "$0")/../alphazero_amd/csrc"
+OUT=../../gpurun_dbg
+mkdir -p $OUT
+for v in now nob nowb; do
+  case $v in now) D="-DAZ_K3_DBG_NOW";; nob) D="-DAZ_K3_DBG_NOB";; nowb) D="-DAZ_K3_DBG_NOW -DAZ_K3_DBG_NOB";; esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -I../../include $D -c az_cnn.hip -o $OUT/az_cnn_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libazamd_$v.so build/az_tree.o build/az_play.o build/az_env.o build/az_traj.o build/az_engine.o $OUT/az_cnn_$v.o
+done
+ls -la $OUT/*.so

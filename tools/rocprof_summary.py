@@ -23,6 +23,18 @@ def kernel_stats(db):
         short = name.split("(")[0][-70:]
         print("%-70s %9d %14.1f %11.2f %11.2f %11.2f %6.2f%%" % (short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3,
                                                               100.0 * tot / total))
+    # Dispatches of one kernel issued on different HIP streams (the engine's cohorts) execute concurrently: the time
+    # the kernel occupies the GPU is the UNION of its [start, end] intervals, not the sum of the durations.
+    print("# busy = union of the dispatch intervals per kernel (equals total_us when dispatches never overlap)")
+    print("%-70s %14s %14s %9s" % ("kernel", "busy_us", "total_us", "overlap"))
+    for name, n, tot, *_ in rows[:6]:
+        busy, last = 0, 0
+        for a, b in c.execute("select start, end from kernels where name = ? order by start", (name,)):
+            lo = max(a, last)
+            if b > lo:
+                busy += b - lo
+                last = b
+        print("%-70s %14.1f %14.1f %8.2fx" % (name.split("(")[0][-70:], busy / 1e3, tot / 1e3, tot / max(busy, 1)))
 
 
 def pmc_stats(db):
@@ -30,12 +42,13 @@ def pmc_stats(db):
     cols = [d[0] for d in c.execute("select * from counters_collection limit 1").description]
     print("# rocprofv3 --pmc   columns available:", ", ".join(cols))
     namecol = "kernel_name" if "kernel_name" in cols else "name"
+    # a counter comes as several rows per dispatch (one per hardware instance): add them up per dispatch first
     rows = list(c.execute(
-        "select %s, counter_name, count(*), sum(value), avg(value) from counters_collection group by 1, 2 order by 1, 2"
-        % namecol))
-    print("%-60s %-28s %9s %20s %18s" % ("kernel", "counter", "dispatches", "sum", "mean/dispatch"))
-    for name, ctr, n, s, a in rows:
-        print("%-60s %-28s %9d %20.1f %18.1f" % (name.split("(")[0][-60:], ctr, n, s, a))
+        "select kn, cn, count(*), sum(v), avg(v), avg(d) from (select %s kn, counter_name cn, dispatch_id, sum(value) v, "
+        "max(duration) d from counters_collection group by 1, 2, 3) group by 1, 2 order by 1, 2" % namecol))
+    print("%-60s %-28s %9s %20s %18s %12s" % ("kernel", "counter", "dispatches", "sum", "mean/dispatch", "avg_dur_us"))
+    for name, ctr, n, s, a, d in rows:
+        print("%-60s %-28s %9d %20.1f %18.1f %12.2f" % (name.split("(")[0][-60:], ctr, n, s, a, (d or 0) / 1e3))
 
 
 if __name__ == "__main__":
