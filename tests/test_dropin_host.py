@@ -1,0 +1,92 @@
+"""Host-side logic of the drop-in mirrors that needs no GPU: plugin loader, configs, format conversions, weight blob
+export.  (Everything that computes runs HIP kernels and is covered by tests/test_gpu_dropin.py.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "alphazero_amd", "dropin")
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    sys.path.insert(0, DROPIN)
+    import environments
+    yield environments
+    sys.path.remove(DROPIN)
+
+
+def test_load_exposes_reference_attributes(dropin):
+    """environments/__init__.py:3-4 + Connect4/__init__.py:1-4: load(name) -> module with Env, CNN, configs."""
+    m = dropin.load("Connect4")
+    for name in ("Env", "CNN", "training_config", "network_config", "env_config", "config", "inspect"):
+        assert hasattr(m, name), name
+    # values on the self-play path (Connect4/config.py:1-21)
+    t = m.config.training_config
+    assert (t["c_puct"], t["n_playout"], t["dirichlet_alpha"], t["temp"], t["first_n_steps"]) == (1.25, 80, 0.7, 1.0, 10)
+    assert dropin.load("TTT").training_config["c_puct"] == 1.0
+    assert dropin.load("NBTTT").training_config["first_n_steps"] == 12
+    assert dropin.load("TTT").Env.N_ACTIONS == 9 and dropin.load("NBTTT").Env.WORDS == 4
+
+
+def test_planes_to_packed_roundtrip_on_golden_states(dropin):
+    """(B,3,6,7) planes recorded from the reference -> packed words -> cells: same stones, same mover."""
+    from environments.network import planes_to_packed
+    tr = np.load(os.path.join(G, "env_traces.npz"))
+    planes = tr["Connect4_state"][:400].reshape(-1, 3, 6, 7)
+    cells = tr["Connect4_cells"][:400].reshape(-1, 6, 7)
+    turn = tr["Connect4_turn"][:400]
+    w = planes_to_packed(planes)
+    for i in range(len(w)):
+        x, o = int(w[i, 0]), int(w[i, 1])
+        assert (o >> 63) == (1 if turn[i] == -1 else 0)
+        o &= ~(1 << 63)
+        for r in range(6):
+            for c in range(7):
+                bit = c * 7 + (5 - r)
+                assert ((x >> bit) & 1) == (cells[i, r, c] == 1)
+                assert ((o >> bit) & 1) == (cells[i, r, c] == -1)
+
+
+def test_state_dict_to_blob_layout(dropin):
+    """blob = every float32 tensor of the state_dict in order, num_batches_tracked skipped; wrong sizes raise."""
+    import torch
+    from alphazero_amd._abi import AzError
+    from environments.network import BLOB_FLOATS, CNN, state_dict_to_blob
+    blob = np.fromfile(os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
+    assert blob.size == BLOB_FLOATS
+    # rebuild a state_dict with the reference's tensor shapes (Connect4/Network.py:31-51) from the blob
+    shapes = [("hidden.0.weight", (128, 3, 3, 3))] + _bn("hidden.1", 128)
+    for b in (4, 5, 6):
+        shapes += [("hidden.%d.conv.0.weight" % b, (128, 128, 3, 3))] + _bn("hidden.%d.conv.1" % b, 128)
+        shapes += [("hidden.%d.conv.4.weight" % b, (128, 128, 1, 1))] + _bn("hidden.%d.conv.5" % b, 128)
+    shapes += [("policy_head.0.weight", (3, 128, 1, 1))] + _bn("policy_head.1", 3)
+    shapes += [("policy_head.4.weight", (7, 126)), ("policy_head.4.bias", (7,))]
+    shapes += [("value_head.0.weight", (1, 128, 1, 1))] + _bn("value_head.1", 1)
+    shapes += [("value_head.4.weight", (3, 42)), ("value_head.4.bias", (3,))]
+    sd, off = {}, 0
+    for k, shp in shapes:
+        if shp is None:
+            sd[k] = torch.tensor(7, dtype=torch.int64)
+            continue
+        n = int(np.prod(shp))
+        sd[k] = torch.from_numpy(blob[off:off + n].reshape(shp).copy())
+        off += n
+    assert off == BLOB_FLOATS
+    assert np.array_equal(state_dict_to_blob(sd), blob)
+    del sd["value_head.4.bias"]
+    with pytest.raises(AzError):
+        state_dict_to_blob(sd)
+    net = CNN(0, device="cuda")
+    with pytest.raises(AzError):
+        net.export_flat()            # no weights yet: loud, unlike NetworkBase.load (q14)
+    with pytest.raises(AzError):
+        CNN(0, h_dim=64)
+
+
+def _bn(prefix, c):
+    return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
+            (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", None)]

@@ -93,3 +93,41 @@ def test_search_with_real_net_move_agreement(eng):
     assert agree >= plies - 1
     assert max(l1) <= 0.1 * S
     e.close()
+
+
+def test_search_result_independent_of_cohorts(blob):
+    """az_config.n_cohorts only changes how the select -> CNN -> backup chains are issued (slot ranges on their own
+    HIP streams); games are independent, so every slot's tree must come out identical for 1, 2, 3 and 4 cohorts."""
+    from alphazero_amd.engine import SelfPlayEngine
+    rng = np.random.default_rng(3)
+    Gn, S = 96, 48
+    flips = rng.integers(0, 2, size=(Gn, S * 3)).astype(np.uint8)
+    roots = []
+    for g in range(Gn):
+        e = orc.Env("Connect4")
+        for _ in range(int(rng.integers(0, 6))):
+            e.step(int(rng.choice(e.valid_move())))
+        roots.append(e.packed())
+    roots = np.array(roots)
+    ref = None
+    for C in (1, 2, 3, 4):
+        eng = SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="stream",
+                             reuse_tree=True, n_cohorts=C)
+        assert eng.n_cohorts == C
+        eng.load_net(blob)
+        eng.set_flip_stream(flips)
+        eng.set_roots(roots)
+        out = []
+        for ply in range(3):
+            eng.search()
+            rc = eng.root_children()
+            a, pi = eng.choose_moves(temp=1e-3)
+            out.append((rc["actions"].copy(), rc["visits"].copy(), rc["q"].view(np.uint32).copy(), a.copy()))
+            eng.advance(a)
+        eng.close()
+        if ref is None:
+            ref = out
+        else:
+            for x, y in zip(ref, out):
+                for u, v in zip(x, y):
+                    assert np.array_equal(u, v), C

@@ -149,3 +149,27 @@ def test_random_playouts_vs_oracle_large(eng, game):
         cur = out["states"]
         st = out
     assert not (st["done"] == 0).any()
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_step_tiled_path_equals_plain_path(eng, game):
+    """the streaming kernel (1024-position tiles, LDS-transposed status stores) and the one-position-per-lane kernel
+    (used for tails and small n) must agree byte for byte: 3 tiles + a ragged tail vs the same positions in chunks
+    of < 1024."""
+    rng = np.random.default_rng(5)
+    A = NA[game]
+    n = 3 * 1024 + 17
+    if game == "NBTTT":
+        opens = np.array([orc.Env.nbttt_open(int(b), int(a), int(p)).packed()
+                          for b, a, p in rng.integers(0, 9, size=(32, 3))])
+        cur = opens[rng.integers(0, 32, size=n)]
+    else:
+        cur = np.tile(orc.Env(game).packed(), (n, 1))
+    for ply in range(7):
+        acts = rng.integers(0, A, size=n).astype(np.int32)   # some illegal on purpose
+        big = eng.env_step_batch(game, cur, acts)
+        for lo in range(0, n, 1000):
+            small = eng.env_step_batch(game, cur[lo:lo + 1000], acts[lo:lo + 1000])
+            for k in ("states", "placed", "winner", "done", "legal"):
+                assert np.array_equal(big[k][lo:lo + 1000], small[k]), (game, ply, k)
+        cur = big["states"]
