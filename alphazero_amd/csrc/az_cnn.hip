@@ -13,7 +13,8 @@
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (the 1e-4 contract rules out bf16), 64 FLOP/clk/SIMD.
 //   * A operand (weights): pre-swizzled on the host into the exact per-lane order, one coalesced 16-byte load per
 //     lane per k-pair (all 4 M-tiles), streamed from L2 (2 MB of weights stay resident in every XCD's 4 MB L2),
-//     software-prefetched PF k-pairs ahead.  No LDS staging: every weight is used by one MFMA per wave.
+//     fetched one block of PF k-pairs ahead, one load per 4-MFMA group.  No LDS staging: every weight is used by one
+//     MFMA per wave.
 //   * B operand (activations): LDS image [ci][pos] (72 KB, 2 workgroups per CU); a 3x3 tap is a constant address
 //     shift plus a per-lane validity bit (zero padding), so the im2col matrix is never materialised.
 //   * conv3x3 -> conv1x1 chaining without LDS: the accumulator tile (row = co on registers, column = pos on lanes)
@@ -44,9 +45,9 @@ struct CnnDev {
     const float4* w3[3];       // [576][64]
     const float4* w1[3];       // [64][64]
     const float* w_head;       // [64][64]
-    const float* b_stem;       // [128]
-    const float* b3[3];
-    const float* b1[3];
+    const float* b_stem;       // [2 h][4 mt][16 r] = bias[co_of(mt, r, h)]: accumulator-layout order, 16-byte loads
+    const float* b3[3];        //   same layout
+    const float* b1[3];        //   same layout
     const float* b_head;       // [4]  policy conv BN bias (3) + value conv BN bias (1)
     const float* plin_w;       // [7][126]
     const float* plin_b;       // [7]
@@ -65,12 +66,7 @@ __device__ inline float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + 
 // co handled by (M-tile mt, accumulator register r, lane half h): the C/D layout of v_mfma_f32_32x32x2_f32.
 __device__ inline int co_of(int mt, int r, int h) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// One 3x3 (or stem) convolution for this wave's 32 positions x 128 output channels.
-//   NKP2 = k-pairs per tap (64 for 128 input channels, 2 for the 4-plane stem image)
-// The weight stream is double buffered in two NAMED register sets (bufA / bufB) and the loop body is unrolled over
-// both, so no register copies exist: a copy `cur = nxt` lets the scheduler sink it next to the MFMA that frees `cur`,
-// which turns the prefetch distance into one MFMA group (measured: MFMA pipe 82 % busy, s_waitcnt vmcnt(7) right
-// after the loads).  Here every load is issued one whole block (U k-pairs = 4U MFMAs = 256 U cycles) before its use.
+// U k-pairs of the weight stream (A operands): one 16-byte load per lane per k-pair.
 template <int U>
 __device__ inline void conv3_load(float4 (&buf)[U], const float4* wl, int k0) {
 #pragma unroll
@@ -98,21 +94,48 @@ __device__ inline void conv3_ldsb(float (&b)[U], const float* bptr, int k0) {
 #endif
     }
 }
+// One block of U k-pairs: 4U MFMAs on the CURRENT operand registers, and -- spread evenly between them, one weight load
+// and one LDS read per 4-MFMA group -- the fetch of the NEXT block's operands, i.e. every operand is requested one
+// block (4U MFMAs = 256 U cycles) before its use.  sched_barrier(0) after every group pins that interleave: without
+// it the scheduler sinks the loads next to their uses to shorten live ranges.  (Measured: load placement -- burst at
+// the block head or interleaved -- does not change the time; the operand streams cost 9 % of MFMA-busy either way,
+// profiles/r01_k3_pmc.txt.)
 template <int NKP2, int U>
-__device__ inline void conv3_block(const float4 (&buf)[U], const float (&b)[U], u32 tapmask, int k0, f32x16 (&acc)[4]) {
+__device__ inline void conv3_step(const float4 (&cw)[U], const float (&cb)[U], float4 (&nw)[U], float (&nb)[U],
+                                  const float4* wl, const float* bptr, int k0, int k1, u32 tapmask, f32x16 (&acc)[4]) {
     const bool valid = (tapmask >> (k0 / NKP2)) & 1u;
+    const int tap1 = k1 / NKP2;          // U divides NKP2: one tap per block of U k-pairs
+    const float* bp1 = bptr + (tap1 / 3 - 1) * 7 + (tap1 % 3 - 1) + (k1 % NKP2) * 2 * XS;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const float bv = valid ? b[u] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].x, bv, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].y, bv, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].z, bv, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, bv, acc[3], 0, 0, 0);
+#ifdef AZ_K3_DBG_NOW
+        nw[u] = make_float4(1e-3f * (float)k1, 2e-3f, 3e-3f, 4e-3f);
+#else
+        nw[u] = wl[(size_t)(k1 + u) * 64];
+#endif
+#ifdef AZ_K3_DBG_NOB
+        nb[u] = 0.25f + (float)((size_t)bp1 & 3);
+#else
+        nb[u] = bp1[u * 2 * XS];
+#endif
+        const float bv = valid ? cb[u] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].x, bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].y, bv, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].z, bv, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].w, bv, acc[3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int NKP2>
-__device__ inline void conv3(const float4* __restrict__ wA, const float* xs, int lane, int pbase, u32 tapmask,
-                             f32x16 (&acc)[4]) {
+// One 3x3 (or stem) convolution for this wave's 32 positions x 128 output channels.
+//   NKP2 = k-pairs per tap (64 for 128 input channels, 2 for the 4-plane stem image)
+// PRE: the caller has already loaded the first weight block into bufA (issued before the preceding epilogue and
+// barrier, so that the L2 latency of a phase's first operands is not exposed at every phase start).
+// Operands live in two NAMED register sets and the loop body is unrolled over both, so no register copies exist; the
+// next-block loads are UNCONDITIONAL (index clamped to the last block, which is simply loaded again): a conditional
+// load makes a control-flow join at which s_waitcnt insertion has to assume the no-load path and drains the queue.
+template <int NKP2, bool PRE>
+__device__ inline void conv3(const float4* __restrict__ wA, float4 (&bufA)[(NKP2 >= PF) ? PF : NKP2], const float* xs,
+                             int lane, int pbase, u32 tapmask, f32x16 (&acc)[4]) {
     const int h = lane >> 5;
     const float* bptr = xs + h * XS + XOFF + pbase;
     const float4* wl = wA + lane;
@@ -120,69 +143,73 @@ __device__ inline void conv3(const float4* __restrict__ wA, const float* xs, int
     constexpr int U = (NKP2 >= PF) ? PF : NKP2;
     constexpr int NB = NK / U;           // blocks
     constexpr int LAST = (NB - 1) * U;
-    float4 bufA[U], bufB[U];
+    float4 bufB[U];
     float bA[U], bB[U];
-    conv3_load<U>(bufA, wl, 0);
+    if (!PRE) conv3_load<U>(bufA, wl, 0);
     conv3_ldsb<NKP2, U>(bA, bptr, 0);
-    // Both operand streams (weights from L2, activations from LDS) are fetched one block ahead of their use.
-    // Loads are UNCONDITIONAL (the index is clamped to the last block, which is simply loaded again): a conditional
-    // load makes a control-flow join at which s_waitcnt insertion has to assume the no-load path and drains the queue.
-    // sched_barrier(0): nothing may be scheduled across -- keeps each load group AHEAD of the block it overlaps
-    // (without it the scheduler sinks the loads below the block to shorten live ranges).
+    // Drain the vector-memory queue once here.  The accumulators and bufA were filled by loads issued before the loop;
+    // s_waitcnt insertion merges that entry state into the loop header and would otherwise emit vmcnt(1) on the first
+    // MFMA group of EVERY iteration (seen in the ISA), i.e. wait for the block that was requested 256 cycles earlier.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
 #pragma unroll 1
     for (int blk = 0; blk + 1 < NB; blk += 2) {
-        conv3_load<U>(bufB, wl, (blk + 1) * U);
-        conv3_ldsb<NKP2, U>(bB, bptr, (blk + 1) * U);
-        __builtin_amdgcn_sched_barrier(0);
-        conv3_block<NKP2, U>(bufA, bA, tapmask, blk * U, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        const int k2 = min((blk + 2) * U, LAST);
-        conv3_load<U>(bufA, wl, k2);
-        conv3_ldsb<NKP2, U>(bA, bptr, k2);
-        __builtin_amdgcn_sched_barrier(0);
-        conv3_block<NKP2, U>(bufB, bB, tapmask, (blk + 1) * U, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        conv3_step<NKP2, U>(bufA, bA, bufB, bB, wl, bptr, blk * U, (blk + 1) * U, tapmask, acc);
+        conv3_step<NKP2, U>(bufB, bB, bufA, bA, wl, bptr, (blk + 1) * U, min((blk + 2) * U, LAST), tapmask, acc);
     }
-    if (NB & 1) conv3_block<NKP2, U>(bufA, bA, tapmask, LAST, acc);
+    if (NB & 1) conv3_step<NKP2, U>(bufA, bA, bufB, bB, wl, bptr, LAST, LAST, tapmask, acc);
 }
 
 // 1x1 convolution whose input is an accumulator-layout tile set held in registers (hin[mt][r]).
 // k-pair (mt, r) covers input channels co_of(mt, r, 0) [lanes 0-31] and co_of(mt, r, 1) [lanes 32-63]: exactly what
 // each lane half already holds, so the register IS the B operand; the host lays the weights out to match.
-// Weights stream in 16 groups of 4 k-pairs through the same two-buffer scheme; group 0 is loaded by the caller
-// (conv1_prefetch) before the SiLU epilogue of the 3x3 convolution so that its latency hides behind that epilogue.
+// Weights stream in 16 groups of C1U k-pairs through the same two-register-set scheme; group 0 is loaded by the
+// caller (conv1_prefetch) before the epilogue so that its latency hides.
 constexpr int C1U = 4;
 __device__ inline void conv1_prefetch(const float4* __restrict__ wB, int lane, float4 (&buf)[C1U]) {
     conv3_load<C1U>(buf, wB + lane, 0);
 }
+// SiLU of the C1U hidden values that conv1 group G consumes (the 3x3 accumulators already hold conv + folded BN bias).
 template <int G>
-__device__ inline void conv1_group(const float4 (&buf)[C1U], const f32x16 (&hin)[4], f32x16 (&acc)[4]) {
+__device__ inline void hidden_act(f32x16 (&hin)[4]) {
+    if constexpr (G < 64 / C1U) {
+#pragma unroll
+        for (int u = 0; u < C1U; u++) {
+            hin[(G * C1U) >> 4][((G * C1U) & 15) + u] = silu(hin[(G * C1U) >> 4][((G * C1U) & 15) + u]);
+        }
+    }
+}
+// group G: C1U k-pairs = 4*C1U MFMAs on cw; between them the loads of group GN into nw and (VALU: exp, rcp) the SiLU
+// of the hidden values group G+1 will consume, so the 3x3 convolution's epilogue overlaps the 1x1 product.
+template <int G, int GN>
+__device__ inline void conv1_step(const float4 (&cw)[C1U], float4 (&nw)[C1U], const float4* wl, f32x16 (&hin)[4],
+                                  f32x16 (&acc)[4]) {
 #pragma unroll
     for (int u = 0; u < C1U; u++) {
+        nw[u] = wl[(size_t)(GN * C1U + u) * 64];
         const float b = hin[(G * C1U) >> 4][((G * C1U) & 15) + u];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].x, b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].y, b, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].z, b, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, b, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].x, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].y, b, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].z, b, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cw[u].w, b, acc[3], 0, 0, 0);
+        if constexpr (G + 1 < 64 / C1U) {
+            constexpr int K = (G + 1) * C1U;
+            hin[K >> 4][(K & 15) + u] = silu(hin[K >> 4][(K & 15) + u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int G>
-__device__ inline void conv1_pair(const float4* wl, float4 (&bufA)[C1U], float4 (&bufB)[C1U], const f32x16 (&hin)[4],
+__device__ inline void conv1_pair(const float4* wl, float4 (&bufA)[C1U], float4 (&bufB)[C1U], f32x16 (&hin)[4],
                                   f32x16 (&acc)[4]) {
     constexpr int LASTG = 64 / C1U - 1;
-    conv3_load<C1U>(bufB, wl, (G + 1) * C1U);
-    __builtin_amdgcn_sched_barrier(0);
-    conv1_group<G>(bufA, hin, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    conv3_load<C1U>(bufA, wl, (G + 2 <= LASTG ? G + 2 : LASTG) * C1U);
-    __builtin_amdgcn_sched_barrier(0);
-    conv1_group<G + 1>(bufB, hin, acc);
-    __builtin_amdgcn_sched_barrier(0);
+    conv1_step<G, G + 1>(bufA, bufB, wl, hin, acc);
+    conv1_step<G + 1, (G + 2 <= LASTG ? G + 2 : LASTG)>(bufB, bufA, wl, hin, acc);
 }
-__device__ inline void conv1(const float4* __restrict__ wB, float4 (&bufA)[C1U], const f32x16 (&hin)[4], int lane,
+__device__ inline void conv1(const float4* __restrict__ wB, float4 (&bufA)[C1U], f32x16 (&hin)[4], int lane,
                              f32x16 (&acc)[4]) {
     const float4* wl = wB + lane;
     float4 bufB[C1U];
+    hidden_act<0>(hin);
     conv1_pair<0>(wl, bufA, bufB, hin, acc);
     conv1_pair<2>(wl, bufA, bufB, hin, acc);
     conv1_pair<4>(wl, bufA, bufB, hin, acc);
@@ -191,6 +218,21 @@ __device__ inline void conv1(const float4* __restrict__ wB, float4 (&bufA)[C1U],
     conv1_pair<10>(wl, bufA, bufB, hin, acc);
     conv1_pair<12>(wl, bufA, bufB, hin, acc);
     conv1_pair<14>(wl, bufA, bufB, hin, acc);
+}
+
+// accumulators start from the folded BatchNorm bias of their channel: 16-byte loads from the accumulator-layout copy
+__device__ inline void bias_load(f32x16 (&a)[4], const float* __restrict__ bp, int h) {
+    const float4* q = reinterpret_cast<const float4*>(bp + h * 64);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 v = q[mt * 4 + j];
+            a[mt][4 * j + 0] = v.x;
+            a[mt][4 * j + 1] = v.y;
+            a[mt][4 * j + 2] = v.z;
+            a[mt][4 * j + 3] = v.w;
+        }
 }
 
 __device__ inline float wave_sum(float v) {
@@ -250,46 +292,42 @@ __global__ __launch_bounds__(256, 2) void k_cnn_forward(CnnDev w, i64 n_host, co
     __syncthreads();
 
     f32x16 acc[4], acc2[4];
+    float4 pre[PF];                    // first weight block of the NEXT 3x3 convolution, loaded a phase early
     // ---- stem: conv3x3(3->128) + BN + SiLU  (Network.py:33-36) ----
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x16)(0.f);
-    conv3<2>(w.w_stem, x0, lane, pbase, tapmask, acc);
+    bias_load(acc, w.b_stem, h);
+    {
+        float4 st[2];
+        conv3<2, false>(w.w_stem, st, x0, lane, pbase, tapmask, acc);
+    }
+    conv3_load<PF>(pre, w.w3[0] + lane, 0);
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = co_of(mt, r, h);
-            xs[co * XS + XOFF + pbase] = silu(acc[mt][r] + w.b_stem[co]);
-        }
+        for (int r = 0; r < 16; r++) xs[co_of(mt, r, h) * XS + XOFF + pbase] = silu(acc[mt][r]);
+    bias_load(acc, w.b3[0], h);
     __syncthreads();
 
     // ---- 3 residual blocks (Network.py:16-27) ----
 #pragma unroll 1
     for (int blk = 0; blk < 3; blk++) {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x16)(0.f);
-        conv3<64>(w.w3[blk], xs, lane, pbase, tapmask, acc);
+        conv3<64, true>(w.w3[blk], pre, xs, lane, pbase, tapmask, acc);   // acc = BN bias + conv3x3   // acc = BN bias + conv3x3
         float4 w1buf[C1U];
         conv1_prefetch(w.w1[blk], lane, w1buf);
-        const float* b3 = w.b3[blk];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][r] = silu(acc[mt][r] + b3[co_of(mt, r, h)]);
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc2[mt] = (f32x16)(0.f);
-        conv1(w.w1[blk], w1buf, acc, lane, acc2);
-        const float* b1 = w.b1[blk];
+        bias_load(acc2, w.b1[blk], h);
+        conv1(w.w1[blk], w1buf, acc, lane, acc2);                          // acc2 = BN bias + conv1x1(SiLU(acc))
+        const int nb = blk < 2 ? blk + 1 : 2;                              // (clamped: the last prefetch is unused)
+        conv3_load<PF>(pre, w.w3[nb] + lane, 0);
         __syncthreads();  // every wave has finished READING xs for this block's conv3x3
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int co = co_of(mt, r, h);
-                float v = silu(xs[co * XS + XOFF + pbase] + acc2[mt][r] + b1[co]);  // F.silu(x + conv(x))
+                const int o = co_of(mt, r, h) * XS + XOFF + pbase;
+                const float v = silu(xs[o] + acc2[mt][r]);   // F.silu(x + conv(x)); BN bias already in acc2
                 acc2[mt][r] = v;
-                xs[co * XS + XOFF + pbase] = v;
+                xs[o] = v;
             }
+        bias_load(acc, w.b3[nb], h);
         __syncthreads();
     }
 
@@ -449,20 +487,25 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
     pack_conv3(w, bn, 3, 4, v4);
     if (rc == AZ_OK) rc = upload(c, v4, &c->d.w_stem);
     vf.resize(128);
-    for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+    auto pack_bias = [&](const Bn& b) {  // [h][mt][r] -> bias of channel co_of(mt, r, h)
+        for (int h = 0; h < 2; h++)
+            for (int mt = 0; mt < 4; mt++)
+                for (int r = 0; r < 16; r++) vf[(h * 4 + mt) * 16 + r] = bn_bias(b, co_of_h(mt, r, h));
+    };
+    pack_bias(bn);
     if (rc == AZ_OK) rc = upload(c, vf, &c->d.b_stem);
     for (int b = 0; b < 3; b++) {  // hidden.4/5/6
         w = br.take((size_t)128 * 128 * 9);
         bn = take_bn(br, 128);
         pack_conv3(w, bn, 128, 128, v4);
         if (rc == AZ_OK) rc = upload(c, v4, &c->d.w3[b]);
-        for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+        pack_bias(bn);
         if (rc == AZ_OK) rc = upload(c, vf, &c->d.b3[b]);
         w = br.take((size_t)128 * 128);
         bn = take_bn(br, 128);
         pack_conv1(w, bn, v4);
         if (rc == AZ_OK) rc = upload(c, v4, &c->d.w1[b]);
-        for (int i = 0; i < 128; i++) vf[i] = bn_bias(bn, i);
+        pack_bias(bn);
         if (rc == AZ_OK) rc = upload(c, vf, &c->d.b1[b]);
     }
     // heads
