@@ -114,3 +114,40 @@ class ReplaySink:
         for i in range(n):
             buffer.store(self.state[i], self.prob[i], self.value[i], self.winner[i], self.next_state[i], self.done[i])
         return n
+
+
+def store_many(buffer, recs, game="Connect4"):
+    """The bulk form of `for data in play_data: buffer.store(*data)` (Pipeline.py:61-62) on the REFERENCE's own
+    ReplayBuffer object (ReplayBuffer.py:10-83): n packed records (device uint8 [n, record_bytes], e.g. from
+    TrajectoryGatherer.gather) are expanded by the unpack kernel straight into buffer.state / prob / value / winner /
+    next_state / done at buffer._ptr, with store()'s ring semantics (wrap at buffer.current_capacity) -- one kernel
+    launch per contiguous piece instead of one Python call and six tensor writes per ply.
+    The buffer's tensors must live on the GPU (ReplayBuffer(..., device='cuda')); returns the index of the first row."""
+    g = _abi.GAME_IDS.get(game, game)
+    L = _abi.lib()
+    n = int(recs.shape[0])
+    first = int(buffer._ptr)
+    if n == 0:
+        return first
+    recs = recs.contiguous()
+    for t in (buffer.state, buffer.prob, buffer.value, buffer.winner, buffer.next_state, buffer.done):
+        if t.device.type != "cuda" or not t.is_contiguous():
+            raise _abi.AzError("store_many needs contiguous device-resident ReplayBuffer tensors (no CPU path)")
+    if recs.device.type != "cuda" or recs.dtype != torch.uint8 or recs.shape[1] != L.az_traj_record_bytes(g):
+        raise _abi.AzError("store_many: records must be a cuda uint8 [n, %d] tensor" % L.az_traj_record_bytes(g))
+    if tuple(buffer.state.shape[1:]) != PLANES[g] or buffer.prob.shape[1] != L.az_n_actions(g):
+        raise _abi.AzError("store_many: buffer shapes do not match game %r" % (game,))
+    cap = int(buffer.current_capacity)
+    vp = C.c_void_p
+    off = 0
+    while off < n:
+        lo = int(buffer._ptr)
+        m = min(n - off, cap - lo)
+        sl = slice(lo, lo + m)
+        _abi.check(L.az_traj_unpack_dev(g, m, vp(recs[off:off + m].data_ptr()), vp(buffer.state[sl].data_ptr()),
+                                        vp(buffer.prob[sl].data_ptr()), vp(buffer.value[sl].data_ptr()),
+                                        vp(buffer.winner[sl].data_ptr()), vp(buffer.next_state[sl].data_ptr()),
+                                        vp(buffer.done[sl].view(torch.uint8).data_ptr())))
+        buffer._ptr = (lo + m) % cap
+        off += m
+    return first

@@ -51,6 +51,36 @@ class Game:
                 dones[-1] = True
                 return winner, zip(states, mcts_probs, winner_z, winner_z, next_states, dones)
 
+    def collect_self_play(self, player, buffer, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
+        """Pipeline.data_collector (Pipeline.py:53-63) in one call: play n_games in lockstep on the device with player's
+        search settings and write every ply into `buffer` (a reference ReplayBuffer whose tensors live on the GPU)
+        with collector.store_many -- trajectories never visit the host.  Under torch.distributed every rank plays
+        n_games and every rank's buffer receives the plies of ALL ranks (RCCL all-gather of packed records).
+        Returns the list of episode lengths of the games stored (data_collector's episode_len is their mean)."""
+        import torch
+        from alphazero_amd.collector import TrajectoryGatherer, store_many
+        from alphazero_amd.engine import SelfPlayEngine
+        m = player.mcts
+        if not hasattr(m.policy, "export_flat"):
+            raise NotImplementedError("batched self-play needs the device evaluator (the drop-in CNN)")
+        game = self.env.GAME
+        dev_index = getattr(m.policy, "device_index", 0)
+        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        G = int(n_slots or min(n_games, 2048))
+        eng = SelfPlayEngine(game, n_games=G, n_playout=m.n_playout, c_puct=m.c_init, evaluator="cnn", flip="random",
+                             reuse_tree=bool(player.is_selfplay), dirichlet_alpha=None if m.deterministic else m.alpha,
+                             rng_seed=rng_seed, move="sample", device=dev_index, game_id_base=rank << 40)
+        try:
+            eng.load_net(m.policy.export_flat())
+            eng.selfplay(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
+            recs = TrajectoryGatherer(eng, torch.device("cuda", dev_index)).gather()
+        finally:
+            eng.close()
+        store_many(buffer, recs, game)
+        done_col = eng.W * 8 + eng.A * 4 + 3
+        ends = torch.nonzero(recs[:, done_col]).flatten().cpu().numpy()
+        return [int(x) for x in np.diff(np.concatenate([[-1], ends]))]
+
     def start_self_play_batch(self, player, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
         """n_games self-play games in lockstep on the device with player's search settings (c_puct, n_playout, alpha,
         train/eval mode) and network.  Returns a list of (winner, [6-tuples]) in completion order, each 6-tuple as

@@ -311,3 +311,31 @@ def test_start_play_and_batched_self_play(dropin):
             last.step(int(np.argmax(diff.sum(0))))
             assert np.array_equal(nxt, last.current_state())
         assert last.done() and last.winPlayer() == winner
+
+
+def test_collect_self_play_into_reference_shaped_buffer(dropin):
+    """Pipeline.data_collector's job in one call: n games on the device, plies written into a ReplayBuffer-shaped object
+    on the GPU by the unpack kernel; lengths, terminal flags and outcome labels are consistent."""
+    import torch
+    from helpers import RefShapedBuffer as _RefShapedBuffer
+    module = dropin["load"]("Connect4")
+    net = module.CNN(0, device="cuda")
+    net.load(os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32"))
+    sp = dropin["player"].AlphaZeroPlayer(net, c_puct=1.25, n_playout=24, alpha=0.7, is_selfplay=1)
+    sp.train()
+    buf = _RefShapedBuffer(3, 4096, 7, 6, 7, torch.device("cuda", 0))
+    lens = dropin["game"].Game(module.Env()).collect_self_play(sp, buf, 40, temp=1.0, first_n_steps=10)
+    assert len(lens) == 40 and all(7 <= n <= 42 for n in lens) and buf._ptr == sum(lens)
+    n = buf._ptr
+    done = buf.done[:n, 0].cpu().numpy()
+    assert done.sum() == 40 and list(np.flatnonzero(done) + 1) == list(np.cumsum(lens))
+    assert not torch.isnan(buf.state[:n]).any() and not torch.isnan(buf.next_state[:n]).any()
+    assert torch.isnan(buf.state[n:]).all()
+    np.testing.assert_allclose(buf.prob[:n].sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+    z = buf.value[:n, 0].cpu().numpy()
+    assert set(np.unique(z)) <= {-1.0, 0.0, 1.0} and np.array_equal(z.astype(np.int32), buf.winner[:n, 0].cpu().numpy())
+    lo = 0
+    for ln in lens:   # inside a game the outcome label alternates with the mover (game.py:52-55)
+        zz = z[lo:lo + ln]
+        assert (zz[::-1][0::2] == zz[-1]).all() and (zz[::-1][1::2] == -zz[-1]).all()
+        lo += ln

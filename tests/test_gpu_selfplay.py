@@ -136,3 +136,38 @@ def test_train_mode_noise_and_random_flips_statistics(E):
     assert st["playouts"] == Gn * S
     base.close()
     noisy.close()
+
+
+from helpers import RefShapedBuffer as _RefShapedBuffer  # noqa: E402
+
+
+def test_store_many_equals_per_ply_store(E):
+    """collector.store_many (one unpack launch per contiguous piece) must leave a reference-shaped ReplayBuffer in
+    exactly the state that Pipeline.data_collector's `for data in play_data: buffer.store(*data)` (Pipeline.py:61-62)
+    leaves it in, ring wrap included."""
+    import torch
+    from alphazero_amd.collector import TrajectoryGatherer, store_many
+    Gn, S = 24, 24
+    eng = E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, evaluator="hash", eval_seed=5, flip="never",
+                           move="first_max")
+    eng.selfplay(Gn, temp=1.0, first_n_steps=6)
+    tr = eng.traj_fetch(clear=False)
+    dev = torch.device("cuda", 0)
+    recs = TrajectoryGatherer(eng, dev).gather()
+    n = len(tr["z"])
+    cap = n - 11                       # smaller than the data: both paths must wrap
+    bulk = _RefShapedBuffer(3, cap, 7, 6, 7, dev)
+    ply = _RefShapedBuffer(3, cap, 7, 6, 7, dev)
+    bulk._ptr = ply._ptr = 5
+    first = store_many(bulk, recs, "Connect4")
+    assert first == 5
+    for i in range(n):                 # the 6-tuples of game.py:58, one store() per ply
+        env = orc.Env.from_packed("Connect4", tr["states"][i])
+        s = env.current_state()
+        env.step(int(tr["action"][i]))
+        ply.store(s, tr["pi"][i], float(tr["z"][i]), float(tr["z"][i]), env.current_state(), bool(tr["done"][i]))
+    assert bulk._ptr == ply._ptr == (5 + n) % cap
+    for name in ("state", "prob", "value", "winner", "next_state", "done"):
+        a, b = getattr(bulk, name).cpu().numpy(), getattr(ply, name).cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), name
+    eng.close()
