@@ -88,6 +88,24 @@ int orc_selfplay_game(orc_mcts *m, const orc_env *start, double temp, int first_
                       uint64_t *states, float *pis, int *players, int *actions_out, float *z, int *winner_out,
                       int *visits_out);
 
+/* az_oracle_pure.c: the pure-MCTS (UCT + rollout) evaluation opponent, MCTS.py:57-63,115-128, utils.py:26-52 */
+typedef struct orc_pure orc_pure;
+orc_pure *orc_pure_new(int game, double c_init, int n_playout, uint64_t seed);
+void orc_pure_free(orc_pure *m);
+void orc_pure_reset_tree(orc_pure *m);
+void orc_pure_set_flips(orc_pure *m, int mode, const uint8_t *bits, int64_t n);
+double orc_uct(double c_init, int c_base, int Np, int n, double Q);
+int orc_rollout_pick(const orc_env *e, uint64_t seed, int nv);
+int orc_rollout(const orc_env *env, uint64_t seed, int64_t *plies_out);
+void orc_pure_playout(orc_pure *m, const orc_env *root_env);
+int orc_pure_get_action(orc_pure *m, const orc_env *env, int *actions, int *visits, double *q, int *n_out);
+void orc_pure_prune_root(orc_pure *m, int action);
+int orc_pure_root_visits(const orc_pure *m);
+double orc_pure_root_q(const orc_pure *m);
+int64_t orc_pure_stat_playouts(const orc_pure *m);
+int64_t orc_pure_stat_levels(const orc_pure *m);
+int64_t orc_pure_stat_rollout_plies(const orc_pure *m);
+
 /* az_oracle_cnn.c */
 #define ORC_CNN_BLOB_FLOATS 500106
 void *orc_cnn_new(const float *blob, int64_t n_floats);

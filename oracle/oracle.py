@@ -82,6 +82,21 @@ def lib():
         "orc_mcts_children": (C.c_int, [vp, ip, C.c_int, ip, ip, fp, fp]),
         "orc_move_probs": (C.c_int, [ip, ip, C.c_int, C.c_double, C.c_int, fp]),
         "orc_selfplay_game": (C.c_int, [vp, envp, C.c_double, C.c_int, C.c_int, C.c_int, u64p, fp, ip, ip, fp, ip, ip]),
+        "orc_pure_new": (vp, [C.c_int, C.c_double, C.c_int, C.c_uint64]),
+        "orc_pure_free": (None, [vp]),
+        "orc_pure_reset_tree": (None, [vp]),
+        "orc_pure_set_flips": (None, [vp, C.c_int, u8p, C.c_int64]),
+        "orc_uct": (C.c_double, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_double]),
+        "orc_rollout_pick": (C.c_int, [envp, C.c_uint64, C.c_int]),
+        "orc_rollout": (C.c_int, [envp, C.c_uint64, P(C.c_int64)]),
+        "orc_pure_playout": (None, [vp, envp]),
+        "orc_pure_get_action": (C.c_int, [vp, envp, ip, ip, P(C.c_double), ip]),
+        "orc_pure_prune_root": (None, [vp, C.c_int]),
+        "orc_pure_root_visits": (C.c_int, [vp]),
+        "orc_pure_root_q": (C.c_double, [vp]),
+        "orc_pure_stat_playouts": (C.c_int64, [vp]),
+        "orc_pure_stat_levels": (C.c_int64, [vp]),
+        "orc_pure_stat_rollout_plies": (C.c_int64, [vp]),
         "orc_cnn_new": (vp, [fp, C.c_int64]),
         "orc_cnn_free": (None, [vp]),
         "orc_cnn_forward": (None, [vp, fp, fp, fp]),
@@ -363,3 +378,73 @@ def move_probs(actions, visits, temp, n_actions):
     pi = np.zeros(n_actions, dtype=np.float32)
     best = lib().orc_move_probs(_ip(a), _ip(v), a.size, float(temp), n_actions, _fp(pi))
     return pi, int(a[best])
+
+
+class PureMCTS:
+    """Oracle MCTS (MCTS.py:90-135: UCT selection + rollout value), the Elo arena's opponent (player.py:71-82)."""
+
+    def __init__(self, game, c_init=4.0, n_playout=2000, seed=0):
+        self.game = GAME_IDS.get(game, game)
+        self.h = lib().orc_pure_new(self.game, float(c_init), int(n_playout), C.c_uint64(seed))
+        self.seed = seed
+        self._keep = []
+
+    def __del__(self):
+        try:
+            lib().orc_pure_free(self.h)
+        except Exception:
+            pass
+
+    def set_flips(self, bits):
+        if bits is None:
+            lib().orc_pure_set_flips(self.h, FLIP_NEVER, None, 0)
+            return
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        self._keep.append(b)
+        lib().orc_pure_set_flips(self.h, FLIP_STREAM, b.ctypes.data_as(C.POINTER(C.c_uint8)), b.size)
+
+    def get_action(self, env):
+        a = np.zeros(9, dtype=np.int32)
+        v = np.zeros(9, dtype=np.int32)
+        q = np.zeros(9, dtype=np.float64)
+        n = C.c_int(0)
+        best = lib().orc_pure_get_action(self.h, C.byref(env.e), _ip(a), _ip(v), q.ctypes.data_as(C.POINTER(C.c_double)),
+                                         C.byref(n))
+        k = n.value
+        return int(best), [int(x) for x in a[:k]], [int(x) for x in v[:k]], q[:k].copy()
+
+    def prune_root(self, action):
+        lib().orc_pure_prune_root(self.h, int(action))
+
+    def reset(self):
+        lib().orc_pure_reset_tree(self.h)
+
+    @property
+    def root_visits(self):
+        return lib().orc_pure_root_visits(self.h)
+
+    @property
+    def root_q(self):
+        return lib().orc_pure_root_q(self.h)
+
+    @property
+    def stat_playouts(self):
+        return lib().orc_pure_stat_playouts(self.h)
+
+    @property
+    def mean_levels(self):
+        return lib().orc_pure_stat_levels(self.h) / max(self.stat_playouts, 1)
+
+    @property
+    def mean_rollout_plies(self):
+        return lib().orc_pure_stat_rollout_plies(self.h) / max(self.stat_playouts, 1)
+
+
+def uct(c_init, c_base, Np, n, Q):
+    return lib().orc_uct(float(c_init), int(c_base), int(Np), int(n), float(Q))
+
+
+def rollout(env, seed):
+    plies = C.c_int64(0)
+    v = lib().orc_rollout(C.byref(env.e), C.c_uint64(seed), C.byref(plies))
+    return v, plies.value

@@ -231,3 +231,43 @@ def test_realnet_search_moves(blob):
         assert np.abs(np.array(vis) - ref_vis).sum() <= 0.05 * S
         t.reset()
         env.step(chosen)
+
+
+# ---------------------------------------------------------------------------- pure MCTS (UCT + rollout, the Elo opponent)
+def _pure_start_env(m):
+    if m["game"] == "NBTTT":
+        return orc.Env.nbttt_open(*m["opening"])
+    return orc.Env(m["game"])
+
+
+def test_uct_bit_exact_vs_reference():
+    """TreeNode.UCT (MCTS.py:57-63): float64 bit patterns recorded from the reference."""
+    d = np.load(os.path.join(G, "pure_mcts.npz"))
+    got = np.array([orc.uct(c, 500, Np, n, Q) for c, Np, n, Q in zip(d["uct_c"], d["uct_Np"], d["uct_n"], d["uct_Q"])])
+    assert np.array_equal(got.view(np.uint64), d["uct_bits"])
+
+
+def test_pure_mcts_vs_reference_games():
+    """MCTS.get_action (MCTS.py:115-128) with utils.policy_value_fn, ply by ply: root children in insertion order,
+    visit counts, float64 Q bit patterns, root statistics and the returned action -- all exact."""
+    d = np.load(os.path.join(G, "pure_mcts.npz"))
+    with open(os.path.join(G, "pure_fixtures.json")) as f:
+        meta = json.load(f)["cases"]
+    for name, m in meta.items():
+        t = orc.PureMCTS(m["game"], m["c_puct"], m["S"], seed=m["seed"])
+        t.set_flips(d[name + "__flips"] if m["has_flips"] else None)
+        env = _pure_start_env(m)
+        for ply in range(m["plies"]):
+            best, acts, vis, q = t.get_action(env)
+            k = int(d[name + "__n_children"][ply])
+            assert acts == list(d[name + "__actions"][ply][:k]), (name, ply)
+            assert vis == list(d[name + "__visits"][ply][:k]), (name, ply)
+            assert np.array_equal(q.view(np.uint64), d[name + "__q_bits"][ply][:k].astype(np.uint64)), (name, ply)
+            assert t.root_visits == d[name + "__root_N"][ply]
+            assert np.float64(t.root_q).view(np.uint64) == d[name + "__root_Q_bits"][ply]
+            assert best == d[name + "__action"][ply], (name, ply)
+            t.prune_root(best if m["reuse"] else -1)
+            env.step(best)
+        w = int(d[name + "__winner"])
+        if w != 99:
+            assert env.done() and env.winPlayer() == w
