@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AZAMD_LIB") or os.path.join(HERE, "libazamd.so")  # AZAMD_LIB: diagnostic builds
 
 GAME_C4, GAME_TTT, GAME_NBTTT = 0, 1, 2
-EVAL_UNIFORM, EVAL_HASH, EVAL_CNN, EVAL_HOST = 0, 1, 2, 3
+EVAL_UNIFORM, EVAL_HASH, EVAL_CNN, EVAL_HOST, EVAL_ROLLOUT, EVAL_ROLLOUT_HASH = 0, 1, 2, 3, 4, 5
 FLIP_NEVER, FLIP_STREAM, FLIP_RANDOM = 0, 1, 2
 MOVE_FIRST_MAX, MOVE_SAMPLE = 0, 1
 GAME_IDS = {"Connect4": GAME_C4, "TTT": GAME_TTT, "NBTTT": GAME_NBTTT}
@@ -34,7 +34,7 @@ class az_config(C.Structure):
 
 class az_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("playouts", "levels", "leaf_evals", "terminal_hits", "children",
-                                         "nodes_used", "games_finished", "plies")]
+                                         "nodes_used", "games_finished", "plies", "rollout_plies")]
 
 
 _P = C.POINTER

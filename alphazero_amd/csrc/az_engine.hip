@@ -468,6 +468,21 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     }
     d.tab = dtab;
     d.tab_n = tab_n;
+    if (cfg->evaluator == AZ_EVAL_ROLLOUT || cfg->evaluator == AZ_EVAL_ROLLOUT_HASH) {
+        // TreeNode.UCT (MCTS.py:57-63) is float64 in the reference; both logarithms come from glibc on the host
+        std::vector<double2> t64((size_t)tab_n);
+        for (int n = 0; n < tab_n; n++)
+            t64[n] = make_double2(cfg->c_init + log((double)(1 + n + e->cfg.c_base) / (double)e->cfg.c_base),
+                                  n > 0 ? log((double)n) : 0.0);
+        double2* dt64 = nullptr;
+        int rc64 = e->dalloc(&dt64, (size_t)tab_n);
+        if (rc64 != AZ_OK) {
+            az_engine_destroy(e);
+            return rc64;
+        }
+        (void)hipMemcpy(dt64, t64.data(), t64.size() * sizeof(double2), hipMemcpyHostToDevice);
+        d.tab64 = dt64;
+    }
     hipError_t he = hipStreamCreate(&e->stream);
     // cohorts only pay off where an evaluator launch sits between select and backup (AZ_EVAL_CNN)
     int C = cfg->n_cohorts;
@@ -569,6 +584,7 @@ int az_get_stats(az_engine* e, az_stats* out) {
     out->nodes_used = used;
     out->games_finished = (i64)st[ST_GAMES];
     out->plies = (i64)st[ST_PLIES];
+    out->rollout_plies = (i64)st[ST_ROLLOUT_PLIES];
     return AZ_OK;
 }
 
@@ -722,6 +738,11 @@ int az_search(az_engine* e, int32_t n_sims) {
         AZ_TRY(launch_search_fused(d, n_sims, e->stream));
         return prof_end(e, e->stream);
     }
+    if (d.evaluator == AZ_EVAL_ROLLOUT || d.evaluator == AZ_EVAL_ROLLOUT_HASH) {
+        AZ_TRY(prof_begin(e, PROF_FUSED, e->stream));
+        AZ_TRY(launch_search_pure(d, n_sims, e->stream));
+        return prof_end(e, e->stream);
+    }
     if (d.evaluator == AZ_EVAL_CNN) {
         if (!e->net) {
             set_error("AZ_EVAL_CNN: call az_net_load first");
@@ -775,6 +796,10 @@ int az_select(az_engine* e, uint64_t* leaf_states, uint8_t* flags) {
     const Dev& d = e->d;
     if (d.flip_mode == AZ_FLIP_STREAM && !d.flip_bits) {
         set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
+        return AZ_ERR_STATE;
+    }
+    if (d.tab64) {
+        set_error("az_select: pure-MCTS engines (AZ_EVAL_ROLLOUT*) are driven with az_search");
         return AZ_ERR_STATE;
     }
     AZ_TRY(launch_select(d, e->stream, true));

@@ -25,7 +25,7 @@ __host__ __device__ inline u32 link_first(u32 l) { return l & LINK_FIRST_MASK; }
 __host__ __device__ inline u32 link_nchild(u32 l) { return (l >> 24) & 15u; }
 __host__ __device__ inline u32 link_action(u32 l) { return l >> 28; }
 
-enum StatIdx { ST_PLAYOUTS = 0, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CHILDREN, ST_GAMES, ST_PLIES, ST_N };
+enum StatIdx { ST_PLAYOUTS = 0, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CHILDREN, ST_GAMES, ST_PLIES, ST_ROLLOUT_PLIES, ST_N };
 
 // Everything a kernel needs, passed by value (all pointers are device memory).
 struct Dev {
@@ -39,6 +39,7 @@ struct Dev {
     u8* active;        // [G] 1 = slot holds a live (non-terminal) game
     const float2* tab; // [tab_n] {f32(c_init + ln((1+Np+c_base)/c_base)), f32(sqrt(Np))}  (host-built, glibc)
     i32 tab_n;
+    const double2* tab64;  // pure MCTS only (else null): {c_init + ln((1+Np+c_base)/c_base), ln(Np)} in float64
     double c_init;
     i32 c_base;
     // leaf evaluation
@@ -94,6 +95,7 @@ int launch_env_flip(int game, i64 n, const u64* in, u64* out, i8* fa, hipStream_
 int launch_puct(double c_init, i32 c_base, i64 n, const i32* Np, const i32* nv, const float* Q, const float* P,
                 const float2* tab, i32 tab_n, float* score, hipStream_t st);
 int launch_search_fused(const Dev& d, int n_sims, hipStream_t st);
+int launch_search_pure(const Dev& d, int n_sims, hipStream_t st);
 int launch_select(const Dev& d, hipStream_t st, bool clear_count);
 int launch_backup(const Dev& d, hipStream_t st);
 int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,

@@ -427,6 +427,205 @@ __global__ __launch_bounds__(256) void k_backup(Dev d) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Pure Monte-Carlo tree search: the reference's MCTS class with utils.policy_value_fn (MCTS.py:57-63,90-128,
+// utils.py:26-52) -- UCT selection, value = one rollout to the end of the game, no network.  It is the opponent of
+// the Elo arena (Pipeline.py:125-135, player.MCTSPlayer).  Everything here is Python-float arithmetic in the
+// reference, i.e. FLOAT64: the node record keeps Q as a double in words (y, z) (priors are not used by UCT):
+//   x = n_visits   (y, z) = Q (float64 bits, meaningless while x == 0)   w = link (as above)
+// tab64 = {c_init + ln((1+Np+c_base)/c_base), ln(Np)} built on the host with glibc; sqrt and divide are IEEE on device.
+// ------------------------------------------------------------------------------------------------------------
+__device__ inline double node_q64(const uint4& r) {
+    return r.x ? __hiloint2double((int)r.z, (int)r.y) : 0.0;  // TreeNode.Q starts at 0 (MCTS.py:15)
+}
+
+template <int LG>
+__device__ inline int group_argmax_first_f64(double score, int gl) {
+    int idx = gl;
+#pragma unroll
+    for (int m = LG / 2; m >= 1; m >>= 1) {
+        double os = __shfl_xor(score, m, LG);
+        int oi = __shfl_xor(idx, m, LG);
+        if (os > score || (os == score && oi < idx)) {
+            score = os;
+            idx = oi;
+        }
+    }
+    return idx;
+}
+
+__device__ inline int nth_set_bit(u32 m, int n) {
+    for (int k = 0; k < n; k++) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
+
+// utils.evaluate_rollout (utils.py:26-40) on a copy of the leaf position: play valid moves to the end, return the
+// outcome seen by the player to move at the leaf.  Move choice (utils.py:49-52 draws np.random.rand per valid move and
+// takes the arg-max = a uniformly random valid move):
+//   AZ_EVAL_ROLLOUT       counter-based device RNG, uniform over the valid moves (statistical parity);
+//   AZ_EVAL_ROLLOUT_HASH  idx = (mix64(fold(words, seed) + 'ROLL') >> 33) % n_valid (the fixture harness's rule: bit parity).
+template <class G>
+__device__ inline int rollout(const Dev& d, int g, typename G::State r, u64 ctr, u32& plies) {
+    const int player = G::turn(r);
+    for (int it = 0; it < 1000; it++) {
+        if (G::winner(r) != 0 || G::full(r)) break;
+        const u32 legal = G::legal(r);
+        const int nv = __popc(legal);
+        int idx;
+        if (d.evaluator == AZ_EVAL_ROLLOUT_HASH) {
+            u64 h = d.eval_seed;
+#pragma unroll
+            for (int i = 0; i < G::W; i++) h = mix64(h ^ r.w[i]);
+            idx = (int)((mix64(h + 0x524F4C4Cull) >> 33) % (u64)nv);
+        } else {
+            idx = (int)(rng_uniform(d.rng_seed, d.game_id[g], ctr, 0x4000u + (u32)it) * (float)nv);
+            idx = idx < nv ? idx : nv - 1;
+        }
+        G::step(r, nth_set_bit(legal, idx));
+        plies++;
+    }
+    const int w = G::winner(r);
+    return w == 0 ? 0 : (w == player ? 1 : -1);
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_search_pure(Dev d, int n_sims) {
+    constexpr int LG = G::LG, GPB = 256 / LG;
+    __shared__ u32 s_idx[GPB][G::MAXD];
+    __shared__ u32 s_N[GPB][G::MAXD];
+    __shared__ double s_Q[GPB][G::MAXD];
+    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int g = blockIdx.x * GPB + grp;
+    if (g >= d.G) return;
+    if (!d.active[g]) return;
+    uint4* nodes = d.nodes + (i64)g * d.cap;
+    const typename G::State rs = load_root_state<G>(d, g);
+    const u32 root = d.root[g];
+    u32 nalloc = d.n_alloc[g];
+    uint4 rr = nodes[root];
+    u32 rN = rr.x, rlink = rr.w;
+    double rQ = node_q64(rr);
+    u32 fpos = d.flip_pos[g];
+    u64 ctr = d.sim_ctr[g];
+    u32 st_levels = 0, st_evals = 0, st_term = 0, st_children = 0, st_rplies = 0;
+    for (int sim = 0; sim < n_sims; sim++) {
+        typename G::State s = rs;  // env.copy()
+        // ---- select_leaf_node(env, UCT=True): MCTS.py:108-113 with TreeNode.UCT (MCTS.py:57-63)
+        u32 node = root, Np = rN, link = rlink;
+        int depth = 0;
+        if (gl == 0) {
+            s_idx[grp][0] = root;
+            s_N[grp][0] = rN;
+            s_Q[grp][0] = rQ;
+        }
+        while (link_nchild(link) > 0 && depth < G::MAXD - 1) {
+            const u32 k = link_nchild(link), first = link_first(link);
+            double2 tb;
+            if (Np < (u32)d.tab_n) tb = d.tab64[Np];
+            else {
+                atomicOr(d.err, 2u);
+                tb = make_double2(d.c_init + log((double)(1u + Np + (u32)d.c_base) / (double)d.c_base), log((double)Np));
+            }
+            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+            double score = -INFINITY;
+            if ((u32)gl < k) {
+                rec = nodes[first + gl];
+                if (rec.x == 0u) score = INFINITY;  // u = inf for an unvisited child; -Q + inf = inf
+                else {
+                    double t = tb.y / (double)rec.x;    // math.log(parent.n_visits) / n_visits
+                    double u = tb.x * sqrt(t);
+                    score = -node_q64(rec) + u;
+                }
+            }
+            const int best = group_argmax_first_f64<LG>(score, gl);
+            const u32 cN = __shfl(rec.x, best, LG), cy = __shfl(rec.y, best, LG), cz = __shfl(rec.z, best, LG);
+            const u32 cl = __shfl(rec.w, best, LG);
+            node = first + (u32)best;
+            depth++;
+            if (gl == 0) {
+                s_idx[grp][depth] = node;
+                s_N[grp][depth] = cN;
+                s_Q[grp][depth] = cN ? __hiloint2double((int)cz, (int)cy) : 0.0;
+            }
+            G::step(s, (int)link_action(cl));
+            Np = cN;
+            link = cl;
+        }
+        Leaf lf;
+        lf.node = node;
+        lf.link = link;
+        lf.depth = depth;
+        lf.flags = 0;
+        lf.tvalue = 0.f;
+        typename G::State aug;
+        leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);  // MCTS.py:117: the flip draw happens on every playout
+        const bool term = lf.flags & 1u, flipped = lf.flags & 2u, sym = lf.flags & 4u;
+        // ---- policy_value_fn(env_aug): uniform priors (unused by UCT) and the rollout value (utils.py:43-46).
+        //      On a finished game the rollout returns at once with the outcome = lf.tvalue.
+        double v = (double)lf.tvalue;
+        if (!term) {
+            v = (double)rollout<G>(d, g, aug, ctr, st_rplies);
+            st_evals++;
+            // ---- node.expand(action_probs) (MCTS.py:119-122, 71-77): children in the evaluated env's ascending
+            //      valid-move order, actions mapped back through flip_action when the playout was mirrored
+            const u32 legal = G::legal(aug);
+            const int nv = __popc(legal);
+            const u32 first = nalloc;
+            if ((i64)first + nv <= d.cap && first + (u32)nv <= LINK_FIRST_MASK) {
+                if (gl < nv) {
+                    int a = nth_set_bit(legal, gl);
+                    if (flipped) a = G::flip_action(sym, a);
+                    nodes[first + gl] = make_uint4(0u, 0u, 0u, (u32)a << 28);
+                }
+                const u32 nl = (lf.link & 0xF0000000u) | first | ((u32)nv << 24);
+                if (gl == 0) reinterpret_cast<u32*>(&nodes[lf.node])[3] = nl;
+                if (lf.node == root) rlink = nl;
+                nalloc = first + (u32)nv;
+                st_children += (u32)nv;
+            } else {
+                atomicOr(d.err, 1u);
+            }
+        } else {
+            st_term++;
+        }
+        // ---- node.update(leaf_value) (MCTS.py:82-87) in float64
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int dd = gl; dd <= depth; dd += LG) {
+            const u32 idx = s_idx[grp][dd], N1 = s_N[grp][dd] + 1u;
+            const double Q = s_Q[grp][dd];
+            const double val = ((depth - dd) & 1) ? -v : v;
+            double dq = val - Q;
+            dq = dq / (double)N1;
+            const double Q1 = Q + dq;
+            u32* w = reinterpret_cast<u32*>(&nodes[idx]);
+            w[0] = N1;
+            w[1] = (u32)__double2loint(Q1);
+            w[2] = (u32)__double2hiint(Q1);
+        }
+        {
+            const double val = (depth & 1) ? -v : v;
+            const u32 N1 = rN + 1u;
+            double dq = val - rQ;
+            dq = dq / (double)N1;
+            rQ = rQ + dq;
+            rN = N1;
+        }
+        st_levels += (u32)depth;
+        ctr++;
+    }
+    if (gl == 0) {
+        d.n_alloc[g] = nalloc;
+        d.flip_pos[g] = fpos;
+        d.sim_ctr[g] = ctr;
+        atomicAdd(&d.stats[ST_PLAYOUTS], (unsigned long long)n_sims);
+        atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)st_levels);
+        atomicAdd(&d.stats[ST_EVALS], (unsigned long long)st_evals);
+        atomicAdd(&d.stats[ST_TERMINAL], (unsigned long long)st_term);
+        atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
+        atomicAdd(&d.stats[ST_ROLLOUT_PLIES], (unsigned long long)st_rplies);
+    }
+}
+
 // (action, visits, Q, prior) of the root children in insertion order: MCTS.py:170-171.
 template <class G>
 __global__ __launch_bounds__(256) void k_root_children(Dev d, i32* actions, i32* visits, float* q, float* prior,
@@ -438,12 +637,12 @@ __global__ __launch_bounds__(256) void k_root_children(Dev d, i32* actions, i32*
     u32 k = link_nchild(rr.w), first = link_first(rr.w);
     if (nch) nch[g] = (i32)k;
     if (rootN) rootN[g] = (i32)rr.x;
-    if (rootQ) rootQ[g] = as_f(rr.y);
+    if (rootQ) rootQ[g] = d.tab64 ? (float)node_q64(rr) : as_f(rr.y);
     for (int i = 0; i < G::A; i++) {
         uint4 c = (u32)i < k ? nodes[first + i] : make_uint4(0u, 0u, 0u, 0xF0000000u);
         if (actions) actions[(i64)g * G::A + i] = (u32)i < k ? (i32)link_action(c.w) : -1;
         if (visits) visits[(i64)g * G::A + i] = (i32)c.x;
-        if (q) q[(i64)g * G::A + i] = as_f(c.y);
+        if (q) q[(i64)g * G::A + i] = d.tab64 ? (float)node_q64(c) : as_f(c.y);
         if (prior) prior[(i64)g * G::A + i] = as_f(c.z);
     }
 }
@@ -487,6 +686,15 @@ int launch_search_fused(const Dev& d, int n_sims, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
         int gpb = 256 / GT::LG;
         k_search_fused<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d, n_sims);
+    });
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
+    AZ_DISPATCH_GAME(game_of(d), {
+        constexpr int gpb = 256 / GT::LG;
+        k_search_pure<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d, n_sims);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;

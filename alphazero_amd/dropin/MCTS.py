@@ -110,9 +110,39 @@ class MCTS:
         else:
             self._root_words = None
 
+    def _is_rollout(self):
+        return type(self.policy).__name__ == "RolloutPolicy"
+
     def get_action(self, env):
-        raise NotImplementedError("the pure-MCTS rollout player (MCTS.py:115-128) is an evaluation opponent, outside "
-                                  "the self-play path (DESIGN.md section 7)")
+        """MCTS.py:125-128 with utils.policy_value_fn: n_playout playouts of UCT selection + one rollout each
+        (float64 arithmetic, like the reference's Python floats), all on the device; returns the
+        (action, child) pair of the most visited root child, first maximum in insertion order."""
+        if not self._is_rollout():
+            raise NotImplementedError("MCTS.get_action runs the reference's own rollout policy (utils.policy_value_fn) "
+                                      "on the device; arbitrary host policies are not supported")
+        game = env.GAME
+        if self._eng is not None and self._game != game:
+            self._eng.close()
+            self._eng = None
+        if self._eng is None:
+            hashed = self.policy.hash_seed is not None
+            seed = self.policy.rng_seed if self.policy.rng_seed is not None else int(np.random.randint(1 << 31))
+            self._eng = SelfPlayEngine(game, n_games=1, n_playout=self.n_playout, c_puct=self.c_init,
+                                       evaluator="rollout_hash" if hashed else "rollout",
+                                       eval_seed=self.policy.hash_seed or 0, flip="stream", reuse_tree=True,
+                                       rng_seed=seed)
+            self._game = game
+            self._root_words = None
+        eng = self._eng
+        self._root_at(env)
+        n = int(self.n_playout)
+        if game != "NBTTT":   # env.random_flip() draws once per playout (MCTS.py:117)
+            bits = np.fromiter((np.random.rand() < 0.5 for _ in range(n)), dtype=np.uint8, count=n)
+            eng.set_flip_stream(bits.reshape(1, n))
+        eng.search(n)
+        root = RootView(eng.root_children())
+        best = max(root.children.items(), key=lambda an: an[1].n_visits)
+        return best
 
 
 class MCTS_AZ(MCTS):

@@ -1,8 +1,8 @@
 """Players with the reference's names and signatures (player.py:12-116).  AlphaZeroPlayer is the hot one."""
 import numpy as np
 
-from MCTS import MCTS_AZ
-from utils import softmax
+from MCTS import MCTS, MCTS_AZ
+from utils import policy_value_fn, softmax
 
 
 class Player:
@@ -54,9 +54,28 @@ class NetworkPlayer(Player):
 
 
 class MCTSPlayer(Player):
-    def __init__(self, c_puct=4, n_playout=2000):
-        raise NotImplementedError("the pure-MCTS rollout opponent (player.py:71-82) is used by the Elo arena only; "
-                                  "it is outside the self-play path (DESIGN.md section 7)")
+    """pure Monte-Carlo tree search, the Elo arena's opponent (player.py:71-82, Pipeline.py:130)."""
+
+    def __init__(self, c_puct=4, n_playout=2000, policy=None):
+        super().__init__()
+        self.mcts = MCTS(policy if policy is not None else policy_value_fn, c_puct, n_playout)
+
+    def train(self):
+        pass
+
+    def eval(self):
+        pass
+
+    def reset_player(self):
+        self.mcts.prune_root(-1)
+
+    def get_action(self, env, *args, **kwargs):
+        """returns what the reference returns: the (action, child) pair of MCTS.get_action, which Game.start_play
+        unpacks as `action, probs, *_` (game.py:20).  The reference then calls prune_root with that PAIR, which is
+        never a key of root.children, so the tree is discarded after every move; so it is here."""
+        pair = self.mcts.get_action(env)
+        self.mcts.prune_root(-1)
+        return pair
 
 
 class AlphaZeroPlayer(Player):

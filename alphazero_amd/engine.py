@@ -9,10 +9,11 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (EVAL_CNN, EVAL_HASH, EVAL_HOST, EVAL_UNIFORM, FLIP_NEVER, FLIP_RANDOM, FLIP_STREAM, GAME_IDS,
+from ._abi import (EVAL_CNN, EVAL_HASH, EVAL_HOST, EVAL_ROLLOUT, EVAL_ROLLOUT_HASH, EVAL_UNIFORM, FLIP_NEVER, FLIP_RANDOM, FLIP_STREAM, GAME_IDS,
                    MOVE_FIRST_MAX, MOVE_SAMPLE, AzError, check, lib, ptr)
 
-EVALS = {"uniform": EVAL_UNIFORM, "hash": EVAL_HASH, "cnn": EVAL_CNN, "host": EVAL_HOST}
+EVALS = {"uniform": EVAL_UNIFORM, "hash": EVAL_HASH, "cnn": EVAL_CNN, "host": EVAL_HOST, "rollout": EVAL_ROLLOUT,
+         "rollout_hash": EVAL_ROLLOUT_HASH}
 FLIPS = {"never": FLIP_NEVER, "stream": FLIP_STREAM, "random": FLIP_RANDOM}
 MOVES = {"first_max": MOVE_FIRST_MAX, "sample": MOVE_SAMPLE}
 

@@ -39,6 +39,10 @@ extern "C" {
 #define AZ_EVAL_HASH 1    /* synthetic deterministic evaluator keyed by the evaluated position (parity)   */
 #define AZ_EVAL_CNN 2     /* fused MFMA CNN forward (Connect4 only), weights from az_net_load            */
 #define AZ_EVAL_HOST 3    /* caller supplies priors/values per leaf batch: az_select / az_backup          */
+/* Pure Monte-Carlo tree search, the reference's MCTS class with utils.policy_value_fn (MCTS.py:57-63,90-128,
+ * utils.py:26-52; the Elo arena's opponent player.MCTSPlayer): UCT selection in float64, value = one rollout. */
+#define AZ_EVAL_ROLLOUT 4      /* rollout moves uniformly random over the valid moves (device RNG)            */
+#define AZ_EVAL_ROLLOUT_HASH 5 /* rollout move = hash of the position (parity with the fixture harness)       */
 
 #define AZ_FLIP_NEVER 0  /* parity: np.random.rand patched to never flip                                  */
 #define AZ_FLIP_STREAM 1 /* parity: explicit bit per playout, az_set_flip_stream                          */
@@ -92,6 +96,7 @@ typedef struct az_stats {
     int64_t nodes_used;    /* sum over games of arena nodes in use                                        */
     int64_t games_finished;
     int64_t plies;
+    int64_t rollout_plies; /* moves played inside rollouts (AZ_EVAL_ROLLOUT*)                             */
 } az_stats;
 
 const char *az_last_error(void);
