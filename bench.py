@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_LEAF = 41.62e6          # MAC = 2 flops, stem + 3 blocks + heads
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# HBM bytes per K3 launch of this workload from the PMC passes of tools/gpu_profile_round.sh (profiles/r01_k3_pmc.txt):
+# FETCH_SIZE 8037.4 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 35.0 KB.  It is the
+# 2.0 MB of weights fetched once per XCD L2 per launch; positions in and outputs out are 33 KB.
+K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8037.4 + 35.0) * 1024
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -178,7 +182,8 @@ def main():
                        "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
             "roofline": {"bound": "mfma", "kernel": "k_cnn_forward", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
+                         "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
+                         "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
                          "launches": cnn["launches"], "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"],
                          "concurrent_cohorts": eng.n_cohorts,
                          "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12},
