@@ -751,31 +751,39 @@ int az_search(az_engine* e, int32_t n_sims) {
         // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
         // (disjoint slots, own leaf list and counter) and are issued round-robin onto their own streams.
         const int C = e->C;
-        Dev dc[AZ_MAX_COHORTS];
+        Dev dc[AZ_MAX_COHORTS][2];   // [cohort][leaf-counter parity]
         hipStream_t cs[AZ_MAX_COHORTS];
         for (int c = 0; c < C; c++) {
-            dc[c] = d;
             const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
-            dc[c].g0 = (i32)lo;
-            dc[c].gn = (i32)(hi - lo);
-            dc[c].eval_count = d.eval_count + 4 * c;
-            dc[c].eval_list = d.eval_list + lo;
+            for (int par = 0; par < 2; par++) {
+                dc[c][par] = d;
+                dc[c][par].g0 = (i32)lo;
+                dc[c][par].gn = (i32)(hi - lo);
+                dc[c][par].eval_count = d.eval_count + 4 * c + par;
+                dc[c][par].eval_list = d.eval_list + lo;
+            }
             cs[c] = c == 0 ? e->stream : e->cstream[c];   // cohort 0 rides on the engine stream (4 hardware queues)
         }
         if (C > 1) {  // fork: the cohort streams start after everything queued on the engine stream
             AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
             for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
         }
+        // Per cohort:  select | CNN, backup+select | CNN, backup+select | ... | CNN, backup.  Playout s counts its
+        // leaves into counter (s & 1); the fused tree step clears the counter the evaluator has just consumed.
+        for (int c = 0; c < C; c++) {
+            AZ_TRY(prof_begin(e, PROF_SELECT, cs[c]));
+            AZ_TRY(launch_select(dc[c][0], cs[c], false));
+            AZ_TRY(prof_end(e, cs[c]));
+        }
         for (int s = 0; s < n_sims; s++) {
+            const int par = s & 1;
             for (int c = 0; c < C; c++) {
-                AZ_TRY(prof_begin(e, PROF_SELECT, cs[c]));
-                AZ_TRY(launch_select(dc[c], cs[c], false));
-                AZ_TRY(prof_end(e, cs[c]));
                 AZ_TRY(prof_begin(e, PROF_CNN, cs[c]));
-                AZ_TRY(cnn_eval_leaves(e->net, dc[c], cs[c]));
+                AZ_TRY(cnn_eval_leaves(e->net, dc[c][par], cs[c]));
                 AZ_TRY(prof_end(e, cs[c]));
                 AZ_TRY(prof_begin(e, PROF_BACKUP, cs[c]));
-                AZ_TRY(launch_backup(dc[c], cs[c]));
+                if (s + 1 < n_sims) AZ_TRY(launch_backup_select(dc[c][par ^ 1], dc[c][par].eval_count, cs[c]));
+                else AZ_TRY(launch_backup(dc[c][par], cs[c]));
                 AZ_TRY(prof_end(e, cs[c]));
             }
         }

@@ -98,6 +98,7 @@ int launch_search_fused(const Dev& d, int n_sims, hipStream_t st);
 int launch_search_pure(const Dev& d, int n_sims, hipStream_t st);
 int launch_select(const Dev& d, hipStream_t st, bool clear_count);
 int launch_backup(const Dev& d, hipStream_t st);
+int launch_backup_select(const Dev& d, u32* stale_count, hipStream_t st);
 int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,
                          float* rootQ, hipStream_t st);
 int launch_reset_trees(const Dev& d, const u8* only /* [G] or null */, hipStream_t st);

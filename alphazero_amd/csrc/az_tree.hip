@@ -329,15 +329,10 @@ __global__ __launch_bounds__(256) void k_search_fused(Dev d, int n_sims) {
 // ------------------------------------------------------------------------------------------------------------
 // Split search: select -> (evaluator kernel or host) -> backup, one playout per game per round.
 // ------------------------------------------------------------------------------------------------------------
+// Bodies of the two halves; `p_*` are this group's LDS path rows.
 template <class G>
-__global__ __launch_bounds__(256) void k_select(Dev d) {
-    constexpr int LG = G::LG, GPB = 256 / LG;
-    __shared__ u32 s_idx[GPB][G::MAXD];
-    __shared__ u32 s_N[GPB][G::MAXD];
-    __shared__ float s_Q[GPB][G::MAXD];
-    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
-    const int g = d.g0 + blockIdx.x * GPB + grp;
-    if (g >= d.g0 + d.gn) return;
+__device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+    constexpr int LG = G::LG;
     if (!d.active[g]) {
         if (gl == 0) d.leaf_flags[g] = 0u;
         return;
@@ -346,15 +341,16 @@ __global__ __launch_bounds__(256) void k_select(Dev d) {
     typename G::State s = load_root_state<G>(d, g);
     const u32 root = d.root[g];
     uint4 rr = nodes[root];
-    Leaf lf = walk<G>(d, nodes, s, root, rr.x, as_f(rr.y), rr.w, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    Leaf lf = walk<G>(d, nodes, s, root, rr.x, as_f(rr.y), rr.w, gl, p_idx, p_N, p_Q);
     typename G::State aug;
     u32 fpos = d.flip_pos[g];
     u64 ctr = d.sim_ctr[g];
     leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int dd = gl; dd <= lf.depth; dd += LG) {  // path: LDS -> HBM, coalesced
-        d.path_idx[(i64)g * G::MAXD + dd] = s_idx[grp][dd];
-        d.path_N[(i64)g * G::MAXD + dd] = s_N[grp][dd];
-        d.path_Q[(i64)g * G::MAXD + dd] = s_Q[grp][dd];
+        d.path_idx[(i64)g * G::MAXD + dd] = p_idx[dd];
+        d.path_N[(i64)g * G::MAXD + dd] = p_N[dd];
+        d.path_Q[(i64)g * G::MAXD + dd] = p_Q[dd];
     }
     if (gl == 0) {
 #pragma unroll
@@ -372,16 +368,8 @@ __global__ __launch_bounds__(256) void k_select(Dev d) {
 }
 
 template <class G>
-__global__ __launch_bounds__(256) void k_backup(Dev d) {
-    constexpr int LG = G::LG, GPB = 256 / LG;
-    __shared__ u32 s_idx[GPB][G::MAXD];
-    __shared__ u32 s_N[GPB][G::MAXD];
-    __shared__ float s_Q[GPB][G::MAXD];
-    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
-    // the evaluator has consumed this round's compacted leaf list: clear the cohort's counter for the next k_select
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d.eval_count = 0u;
-    const int g = d.g0 + blockIdx.x * GPB + grp;
-    if (g >= d.g0 + d.gn) return;
+__device__ inline void backup_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+    constexpr int LG = G::LG;
     const u32 flags = d.leaf_flags[g];
     if (!(flags & 8u)) return;
     uint4* nodes = d.nodes + (i64)g * d.cap;
@@ -390,12 +378,12 @@ __global__ __launch_bounds__(256) void k_backup(Dev d) {
     lf.flags = flags & 7u;
     lf.tvalue = d.leaf_tvalue[g];
     for (int dd = gl; dd <= lf.depth; dd += LG) {  // path: HBM -> LDS
-        s_idx[grp][dd] = d.path_idx[(i64)g * G::MAXD + dd];
-        s_N[grp][dd] = d.path_N[(i64)g * G::MAXD + dd];
-        s_Q[grp][dd] = d.path_Q[(i64)g * G::MAXD + dd];
+        p_idx[dd] = d.path_idx[(i64)g * G::MAXD + dd];
+        p_N[dd] = d.path_N[(i64)g * G::MAXD + dd];
+        p_Q[dd] = d.path_Q[(i64)g * G::MAXD + dd];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    lf.node = s_idx[grp][lf.depth];
+    lf.node = p_idx[lf.depth];
     lf.link = nodes[lf.node].w;
     typename G::State aug;
 #pragma unroll
@@ -411,12 +399,11 @@ __global__ __launch_bounds__(256) void k_backup(Dev d) {
     }
     const u32 root = d.root[g];
     u32 nalloc = d.n_alloc[g];
-    u32 rN = s_N[grp][0], rlink = nodes[root].w;
-    float rQ = s_Q[grp][0];
+    u32 rN = p_N[0], rlink = nodes[root].w;
+    float rQ = p_Q[0];
     u32 st_children = 0;
     u64 ctr = d.sim_ctr[g];
-    finish<G>(d, g, nodes, aug, lf, probs, value, gl, nalloc, root, rN, rQ, rlink, s_idx[grp], s_N[grp], s_Q[grp], ctr,
-              st_children);
+    finish<G>(d, g, nodes, aug, lf, probs, value, gl, nalloc, root, rN, rQ, rlink, p_idx, p_N, p_Q, ctr, st_children);
     if (gl == 0) {
         d.n_alloc[g] = nalloc;
         d.sim_ctr[g] = ctr + 1;
@@ -424,6 +411,28 @@ __global__ __launch_bounds__(256) void k_backup(Dev d) {
         atomicAdd(&d.stats[ST_PLAYOUTS], 1ull);
         atomicAdd(&d.stats[(flags & 1u) ? ST_TERMINAL : ST_EVALS], 1ull);
         atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
+    }
+}
+
+// mode bit0: backup of the evaluated playout, bit1: select of the next one.  Between two evaluator launches the
+// engine issues ONE kernel that finishes playout i and walks playout i+1 (same group, same wave, so the walk sees the
+// statistics the backup has just written), instead of a backup launch followed by a select launch.
+template <class G>
+__global__ __launch_bounds__(256) void k_tree_step(Dev d, int mode, u32* clear_count) {
+    constexpr int LG = G::LG, GPB = 256 / LG;
+    __shared__ u32 s_idx[GPB][G::MAXD];
+    __shared__ u32 s_N[GPB][G::MAXD];
+    __shared__ float s_Q[GPB][G::MAXD];
+    // clear_count: a leaf counter that the evaluator has already consumed and that nothing in THIS launch counts
+    // into (the select half of this launch counts into d.eval_count, which is a different counter: see the engine).
+    if (clear_count && blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0u;
+    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int g = d.g0 + blockIdx.x * GPB + grp;
+    if (g >= d.g0 + d.gn) return;
+    if (mode & 1) backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    if (mode & 2) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
     }
 }
 
@@ -700,23 +709,26 @@ int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
     return AZ_OK;
 }
 
-int launch_select(const Dev& d, hipStream_t st, bool clear_count) {
-    if (clear_count) AZ_HIP(hipMemsetAsync(d.eval_count, 0, sizeof(u32), st));
+// mode 2 = select, 1 = backup, 3 = backup of playout i then select of playout i+1
+static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
-        int gpb = 256 / GT::LG;
-        k_select<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
+        constexpr int gpb = 256 / GT::LG;
+        k_tree_step<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
-
-int launch_backup(const Dev& d, hipStream_t st) {
-    AZ_DISPATCH_GAME(game_of(d), {
-        int gpb = 256 / GT::LG;
-        k_backup<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d);
-    });
-    AZ_HIP(hipGetLastError());
-    return AZ_OK;
+int launch_select(const Dev& d, hipStream_t st, bool clear_count) {
+    if (clear_count) AZ_HIP(hipMemsetAsync(d.eval_count, 0, sizeof(u32), st));
+    return launch_tree_step(d, 2, nullptr, st);
+}
+// the evaluator has consumed d.eval_count: the backup clears it for the next selection
+int launch_backup(const Dev& d, hipStream_t st) { return launch_tree_step(d, 1, d.eval_count, st); }
+// backup + select in one launch.  The counter the new selection counts into (d.eval_count) cannot be cleared inside the
+// launch (workgroups that already select count while others still back up), so evaluator rounds alternate between two
+// counters: `stale_count` is the one the evaluator has just consumed; it is cleared here for the round after next.
+int launch_backup_select(const Dev& d, u32* stale_count, hipStream_t st) {
+    return launch_tree_step(d, 3, stale_count, st);
 }
 
 int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,
