@@ -180,3 +180,30 @@ def test_arena_alphazero_beats_pure_mcts(E):
     assert az_wins > 3 * pure_wins
     az.close()
     pure.close()
+
+
+def test_network_player_arena(E):
+    """Pipeline.select_best_player's pairing (Pipeline.py:137-163) as a batch: NetworkPlayer(net, False) against a
+    NetworkPlayer with damaged weights.  The intact net must score well above the threshold the reference uses (0.65)."""
+    from alphazero_amd.arena import NetworkSide, play_sides, win_rate
+    blob = np.fromfile(os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
+    rng = np.random.default_rng(0)
+    bad = blob.copy()
+    bad[-(7 * 126 + 7 + 128 + 4 + 3 * 42 + 3):] = rng.normal(0, 0.05, size=7 * 126 + 7 + 128 + 4 + 3 * 42 + 3)  # heads
+    Gn = 128
+    cur = E.SelfPlayEngine("Connect4", n_games=1, n_playout=1, evaluator="cnn")
+    cur.load_net(blob)
+    old = E.SelfPlayEngine("Connect4", n_games=1, n_playout=1, evaluator="cnn")
+    old.load_net(bad)
+    a = NetworkSide(cur, deterministic=False, seed=1)
+    b = NetworkSide(old, deterministic=False, seed=2)
+    wx, px = play_sides("Connect4", Gn, 2, a, b)
+    wo, po = play_sides("Connect4", Gn, 2, b, a)
+    wr = win_rate(wx, wo)
+    print("network arena: win rate of the intact net %.3f over %d games, mean plies %.1f" % (wr, 2 * Gn, np.concatenate([px, po]).mean()))
+    assert (px >= 7).all() and wr > 0.65
+    # deterministic players: every game of the batch is the same game
+    wd, pd = play_sides("Connect4", 8, 2, NetworkSide(cur, True), NetworkSide(cur, True))
+    assert (wd == wd[0]).all() and (pd == pd[0]).all()
+    cur.close()
+    old.close()
