@@ -22,6 +22,7 @@
 //   * Activations never leave the CU; HBM traffic per leaf = 16 B in + 32 B out.
 // FLOPs per leaf: 41.62 MFLOP.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -38,7 +39,6 @@ constexpr int SPB = 3;            // samples per workgroup
 constexpr int XS = 144;           // LDS row stride in floats: 8 guard | 128 positions | 8 guard
 constexpr int XOFF = 8;
 constexpr int PF = 8;             // weight prefetch depth (k-pairs)
-constexpr float BN_EPS = 1e-5f;
 
 struct CnnDev {
     const float4* w_stem;      // [18][64]
@@ -58,6 +58,7 @@ struct CnnDev {
 struct Cnn {
     CnnDev d;
     std::vector<void*> allocs;
+    CnnW* wino = nullptr;  // the product kernel's weights; null only in the AZ_K3_DIRECT=1 diagnostic mode
 };
 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) are far inside the 1e-4 contract.
@@ -404,27 +405,6 @@ __global__ __launch_bounds__(256, 2) void k_cnn_forward(CnnDev w, i64 n_host, co
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct BlobReader {
-    const float* p;
-    const float* take(size_t n) {
-        const float* r = p;
-        p += n;
-        return r;
-    }
-};
-struct Bn {
-    const float *g, *b, *m, *v;
-};
-static Bn take_bn(BlobReader& br, size_t c) {
-    Bn bn;
-    bn.g = br.take(c);
-    bn.b = br.take(c);
-    bn.m = br.take(c);
-    bn.v = br.take(c);
-    return bn;
-}
-static inline float bn_scale(const Bn& bn, int c) { return bn.g[c] / sqrtf(bn.v[c] + BN_EPS); }
-static inline float bn_bias(const Bn& bn, int c) { return bn.b[c] - bn.m[c] * bn_scale(bn, c); }
 static inline int co_of_h(int mt, int r, int h) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <class T>
@@ -439,7 +419,7 @@ static int upload(Cnn* c, const std::vector<T>& v, const T** out) {
 
 // 3x3 conv weights OIHW (co, ci, 3, 3) with BN scale folded -> per-lane A operand stream [k-pair][lane] float4.
 // k = tap * cin_pad + ci  (cin_pad = 128, or 4 for the stem whose 4th input plane is zero).
-static void pack_conv3(const float* wt, const Bn& bn, int cin, int cin_pad, std::vector<float4>& out) {
+static void pack_conv3(const float* wt, const CnnBn& bn, int cin, int cin_pad, std::vector<float4>& out) {
     const int nk = 9 * cin_pad;
     out.assign((size_t)(nk / 2) * 64, make_float4(0, 0, 0, 0));
     for (int kp = 0; kp < nk / 2; kp++)
@@ -449,13 +429,13 @@ static void pack_conv3(const float* wt, const Bn& bn, int cin, int cin_pad, std:
             if (ci < cin)
                 for (int mt = 0; mt < 4; mt++) {
                     int co = mt * 32 + (lane & 31);
-                    v[mt] = wt[((size_t)co * cin + ci) * 9 + tap] * bn_scale(bn, co);
+                    v[mt] = wt[((size_t)co * cin + ci) * 9 + tap] * cnn_bn_scale(bn, co);
                 }
             out[(size_t)kp * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
 }
 // 1x1 conv weights (co, ci) with BN scale folded, reduction index ordered like an accumulator tile (see conv1()).
-static void pack_conv1(const float* wt, const Bn& bn, std::vector<float4>& out) {
+static void pack_conv1(const float* wt, const CnnBn& bn, std::vector<float4>& out) {
     out.assign((size_t)64 * 64, make_float4(0, 0, 0, 0));
     for (int mts = 0; mts < 4; mts++)
         for (int r = 0; r < 16; r++)
@@ -464,7 +444,7 @@ static void pack_conv1(const float* wt, const Bn& bn, std::vector<float4>& out) 
                 float v[4];
                 for (int mt = 0; mt < 4; mt++) {
                     int co = mt * 32 + (lane & 31);
-                    v[mt] = wt[(size_t)co * HD + k] * bn_scale(bn, co);
+                    v[mt] = wt[(size_t)co * HD + k] * cnn_bn_scale(bn, co);
                 }
                 out[(size_t)(mts * 16 + r) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -477,32 +457,42 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
     }
     Cnn* c = new Cnn();
     memset(&c->d, 0, sizeof(c->d));
-    BlobReader br{blob};
+    const char* direct = getenv("AZ_K3_DIRECT");  // diagnostic A/B switch; the product kernel is the Winograd form
+    if (!(direct && direct[0] == '1')) {
+        int rcw = cnnw_create(blob, n_floats, &c->wino);
+        if (rcw != AZ_OK) {
+            delete c;
+            return rcw;
+        }
+        *out = c;
+        return AZ_OK;
+    }
+    CnnBlobReader br{blob};
     int rc = AZ_OK;
     std::vector<float4> v4;
     std::vector<float> vf;
     // hidden.0 / hidden.1
     const float* w = br.take(128 * 3 * 9);
-    Bn bn = take_bn(br, 128);
+    CnnBn bn = cnn_take_bn(br, 128);
     pack_conv3(w, bn, 3, 4, v4);
     if (rc == AZ_OK) rc = upload(c, v4, &c->d.w_stem);
     vf.resize(128);
-    auto pack_bias = [&](const Bn& b) {  // [h][mt][r] -> bias of channel co_of(mt, r, h)
+    auto pack_bias = [&](const CnnBn& b) {  // [h][mt][r] -> bias of channel co_of(mt, r, h)
         for (int h = 0; h < 2; h++)
             for (int mt = 0; mt < 4; mt++)
-                for (int r = 0; r < 16; r++) vf[(h * 4 + mt) * 16 + r] = bn_bias(b, co_of_h(mt, r, h));
+                for (int r = 0; r < 16; r++) vf[(h * 4 + mt) * 16 + r] = cnn_bn_bias(b, co_of_h(mt, r, h));
     };
     pack_bias(bn);
     if (rc == AZ_OK) rc = upload(c, vf, &c->d.b_stem);
     for (int b = 0; b < 3; b++) {  // hidden.4/5/6
         w = br.take((size_t)128 * 128 * 9);
-        bn = take_bn(br, 128);
+        bn = cnn_take_bn(br, 128);
         pack_conv3(w, bn, 128, 128, v4);
         if (rc == AZ_OK) rc = upload(c, v4, &c->d.w3[b]);
         pack_bias(bn);
         if (rc == AZ_OK) rc = upload(c, vf, &c->d.b3[b]);
         w = br.take((size_t)128 * 128);
-        bn = take_bn(br, 128);
+        bn = cnn_take_bn(br, 128);
         pack_conv1(w, bn, v4);
         if (rc == AZ_OK) rc = upload(c, v4, &c->d.w1[b]);
         pack_bias(bn);
@@ -510,11 +500,11 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
     }
     // heads
     const float* pconv = br.take(3 * 128);
-    Bn pbn = take_bn(br, 3);
+    CnnBn pbn = cnn_take_bn(br, 3);
     const float* plw = br.take(7 * 126);
     const float* plb = br.take(7);
     const float* vconv = br.take(128);
-    Bn vbn = take_bn(br, 1);
+    CnnBn vbn = cnn_take_bn(br, 1);
     const float* vlw = br.take(3 * 42);
     const float* vlb = br.take(3);
     std::vector<float> wh((size_t)64 * 64, 0.f);
@@ -523,12 +513,12 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
             for (int lane = 0; lane < 64; lane++) {
                 int k = co_of_h(mts, r, lane >> 5), row = lane & 31;
                 float v = 0.f;
-                if (row < 3) v = pconv[row * 128 + k] * bn_scale(pbn, row);
-                else if (row == 3) v = vconv[k] * bn_scale(vbn, 0);
+                if (row < 3) v = pconv[row * 128 + k] * cnn_bn_scale(pbn, row);
+                else if (row == 3) v = vconv[k] * cnn_bn_scale(vbn, 0);
                 wh[(size_t)(mts * 16 + r) * 64 + lane] = v;
             }
     if (rc == AZ_OK) rc = upload(c, wh, &c->d.w_head);
-    std::vector<float> bh = {bn_bias(pbn, 0), bn_bias(pbn, 1), bn_bias(pbn, 2), bn_bias(vbn, 0)};
+    std::vector<float> bh = {cnn_bn_bias(pbn, 0), cnn_bn_bias(pbn, 1), cnn_bn_bias(pbn, 2), cnn_bn_bias(vbn, 0)};
     if (rc == AZ_OK) rc = upload(c, bh, &c->d.b_head);
     if (rc == AZ_OK) rc = upload(c, std::vector<float>(plw, plw + 7 * 126), &c->d.plin_w);
     if (rc == AZ_OK) rc = upload(c, std::vector<float>(plb, plb + 7), &c->d.plin_b);
@@ -544,6 +534,7 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
 
 void cnn_destroy(Cnn* c) {
     if (!c) return;
+    cnnw_destroy(c->wino);
     for (void* q : c->allocs) (void)hipFree(q);
     delete c;
 }
@@ -551,6 +542,7 @@ void cnn_destroy(Cnn* c) {
 int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, float* probs, float* value,
                 hipStream_t st) {
     if (n <= 0) return AZ_OK;
+    if (c->wino) return cnnw_launch(c->wino, (unsigned)n, n, nullptr, nullptr, states_dev, logp, logv, probs, value, st);
     const unsigned grid = (unsigned)((n + SPB - 1) / SPB);
     k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, n, nullptr, nullptr, states_dev, logp, logv, probs, value);
     AZ_HIP(hipGetLastError());
@@ -558,6 +550,9 @@ int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, 
 }
 
 int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
+    if (c->wino)   // the cohort's slots bound its leaf count
+        return cnnw_launch(c->wino, (unsigned)d.gn, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
+                           d.eval_probs, d.eval_value, st);
     const unsigned grid = (unsigned)((d.gn + SPB - 1) / SPB);   // the cohort's slots bound its leaf count
     k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
                                                     d.eval_probs, d.eval_value);

@@ -37,9 +37,9 @@ def test_cnn_vs_reference_golden(eng):
     np.testing.assert_allclose(value, d["value"], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 127, 1000])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 11, 127, 1000])
 def test_cnn_ragged_batches_vs_oracle(eng, blob, n):
-    """batch sizes that do not fill the 3-sample workgroup tile; random reachable positions."""
+    """batch sizes that do not fill the 5-sample (Winograd kernel) or 3-sample (direct kernel) workgroup tile; random reachable positions."""
     rng = np.random.default_rng(n)
     envs = []
     while len(envs) < n:
