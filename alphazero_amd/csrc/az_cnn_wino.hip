@@ -37,6 +37,7 @@ constexpr int WCOLS = WS * 12;    // tile columns per workgroup
 constexpr int WP = WS * NPOS;     // 210 positions
 constexpr int WRS = 213;          // LDS row stride (floats); [210..212] stay zero
 constexpr int WZ = WP;            // index of the zero cell in every row
+constexpr int WDUMP = WP + 1;     // cell of every row that takes the stores of outputs that do not exist
 constexpr int NKS = HD / 4;       // k-steps of 4 input channels
 constexpr int MTP = 2;            // M-tiles (16 output channels each) per pass
 constexpr int NPASS = 8 / MTP;
@@ -134,6 +135,14 @@ __device__ inline void wfence8(const float4 (&w)[4 * MTP]) {
         asm volatile("" ::"v"(w[0].x), "v"(w[1].x), "v"(w[2].x), "v"(w[3].x), "v"(w[4].x), "v"(w[5].x), "v"(w[6].x), "v"(w[7].x));
     else
         asm volatile("" ::"v"(w[0].x), "v"(w[1].x), "v"(w[2].x), "v"(w[3].x));
+}
+__device__ inline void wfence2(const float4 (&w)[2]) { asm volatile("" ::"v"(w[0].x), "v"(w[1].x)); }
+__device__ inline void wmfma_operands(float (&y)[4]) {
+    asm volatile("s_nop 1" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+// 8-pass MFMA result -> the epilogue's reads of the 1x1 tiles
+__device__ inline void wmfma_drain2(f32x4 (&a)[8][4]) {
+    asm volatile("s_nop 15" : "+a"(a[4][3]), "+a"(a[5][3]), "+a"(a[6][3]), "+a"(a[7][3]));
 }
 __device__ inline void wfence16(const float (&d)[16]) {
     asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]),
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     const int col_id = wave * 16 + nn;
     const bool cvalid = col_id < WCOLS;
     int off[16];      // patch cell (i, j) -> index in an activation row, or the zero cell
-    int opos[4];      // output (a, b) -> position index (garbage when !ovalid)
+    int opos[4];      // output (a, b) -> position index (the dump cell when !ovalid)
     bool ovalid[4];
     {
         const int s = col_id / 12, t = col_id % 12, tr = t / 4, tc = t % 4;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 ovalid[2 * a + b] = cvalid && (2 * tc + b < 7);
-                opos[2 * a + b] = ovalid[2 * a + b] ? (s * NPOS + (2 * tr + a) * 7 + 2 * tc + b) : 0;
+                opos[2 * a + b] = ovalid[2 * a + b] ? (s * NPOS + (2 * tr + a) * 7 + 2 * tc + b) : WDUMP;
             }
     }
     __syncthreads();
@@ -452,33 +461,46 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
                 float4(&cu)[2] = (kk & 1) ? ub : ua;
                 float4(&nu)[2] = (kk & 1) ? ua : ub;
                 wload4<2>(nu, w1p + (size_t)(kk + 1 < 4 * MTP ? kk + 1 : kk) * 2 * 64);
+                wfence2(cu);          // one wait for this group's weights
+                wmfma_operands(y);    // VALU result -> MFMA operand wait states (the asm MFMAs are not padded)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    acc2[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[0].x, y[c], acc2[0][c], 0, 0, 0);
-                    acc2[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[0].y, y[c], acc2[1][c], 0, 0, 0);
-                    acc2[2][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[0].z, y[c], acc2[2][c], 0, 0, 0);
-                    acc2[3][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[0].w, y[c], acc2[3][c], 0, 0, 0);
-                    acc2[4][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[1].x, y[c], acc2[4][c], 0, 0, 0);
-                    acc2[5][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[1].y, y[c], acc2[5][c], 0, 0, 0);
-                    acc2[6][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[1].z, y[c], acc2[6][c], 0, 0, 0);
-                    acc2[7][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cu[1].w, y[c], acc2[7][c], 0, 0, 0);
+                    wmfma(acc2[0][c], cu[0].x, y[c]);
+                    wmfma(acc2[1][c], cu[0].y, y[c]);
+                    wmfma(acc2[2][c], cu[0].z, y[c]);
+                    wmfma(acc2[3][c], cu[0].w, y[c]);
+                    wmfma(acc2[4][c], cu[1].x, y[c]);
+                    wmfma(acc2[5][c], cu[1].y, y[c]);
+                    wmfma(acc2[6][c], cu[1].z, y[c]);
+                    wmfma(acc2[7][c], cu[1].w, y[c]);
                 }
             }
         }
+        wmfma_drain2(acc2);
         WTS(200 + blk * 3);
         __syncthreads();  // every wave has finished READING xs for this block's 3x3 convolution
         WTS(200 + blk * 3 + 1);
 #pragma unroll
-        for (int mt2 = 0; mt2 < 8; mt2++)
+        for (int mt2 = 0; mt2 < 8; mt2++) {
+            // F.silu(x + conv(x)); BN bias already in acc2.  16 reads, 16 SiLUs, 16 writes per tile (one LDS wait each
+            // way); cells that do not exist (output column 7, columns past the 60th) go to the row's dump cell.
+            float xv[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) xv[4 * c + r] = xs[(16 * mt2 + 4 * g + r) * WRS + opos[c]];
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int o = (16 * mt2 + 4 * g + r) * WRS + opos[c];
-                    const float v = wsilu(xs[o] + acc2[mt2][c][r]);   // F.silu(x + conv(x)); BN bias already in acc2
-                    acc2[mt2][c][r] = v;
-                    if (ovalid[c]) xs[o] = v;
+                    xv[4 * c + r] = wsilu(xv[4 * c + r] + acc2[mt2][c][r]);
+                    acc2[mt2][c][r] = xv[4 * c + r];
                 }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) xs[(16 * mt2 + 4 * g + r) * WRS + opos[c]] = xv[4 * c + r];
+        }
         __syncthreads();
         WTS(200 + blk * 3 + 2);
     }
