@@ -162,63 +162,58 @@ __device__ inline void wino_in_op(const float (&d)[16], float (&t)[16], float (&
     }
 }
 
-// slice P of a k-step: MFMA number P (M-tile P / 16 of the pass, transform point P % 16) and, behind it, this slice's
-// share of the look-ahead work.  fp32 MFMAs execute at the vector-ALU rate and VALU work does NOT hide under them
-// (measured: tools/ubench/mfma_rate.hip), so the look-ahead is spread thin only to keep latencies covered.
+// MFMA number P of a k-step: M-tile P / 16 of the pass, transform point P % 16.
 template <int P>
-__device__ inline void wino_slice(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
-                                  const float4* wnext, const float (&dt)[16], float (&t)[16], float (&nv)[16],
-                                  float (&dl)[16], const float* xs, const int (&xo)[16], int kl, f32x4 (&acc)[16 * MTP]) {
+__device__ inline void wino_mfma(const float4 (&cw)[4 * MTP], const float (&cv)[16], f32x4 (&acc)[16 * MTP]) {
     constexpr int Q = P >> 2;
     const float a = (P & 3) == 0 ? cw[Q].x : (P & 3) == 1 ? cw[Q].y : (P & 3) == 2 ? cw[Q].z : cw[Q].w;
     wmfma(acc[P], a, cv[P & 15]);
-    if constexpr (P < 4 * MTP) {
-#ifdef AZ_K3_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
-#else
-        nw[P] = wnext[P * 64];
-#endif
-    }
-    if constexpr (P % MTP == 0) {
-#ifdef AZ_K3_DBG_NOB   // diagnostic: no LDS patch reads
-#else
-        dl[P / MTP] = wlds(xs, xo[P / MTP], kl);
-#endif
-    }
-#ifndef AZ_K3_DBG_NOXF  // diagnostic: no input transform
-    if constexpr (MTP == 1) {
-        wino_in_op<2 * P>(dt, t, nv);
-        wino_in_op<2 * P + 1>(dt, t, nv);
-    } else {
-        wino_in_op<P>(dt, t, nv);
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
 }
-template <int P>
-struct WinoSlices {
-    static __device__ inline void run(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
-                                      const float4* wnext, const float (&dt)[16], float (&t)[16], float (&nv)[16],
-                                      float (&dl)[16], const float* xs, const int (&xo)[16], int kl,
-                                      f32x4 (&acc)[16 * MTP]) {
-        wino_slice<P>(cw, cv, nw, wnext, dt, t, nv, dl, xs, xo, kl, acc);
-        if constexpr (P + 1 < 16 * MTP) WinoSlices<P + 1>::run(cw, cv, nw, wnext, dt, t, nv, dl, xs, xo, kl, acc);
+template <int P, int END>
+struct WinoMfmas {
+    static __device__ inline void run(const float4 (&cw)[4 * MTP], const float (&cv)[16], f32x4 (&acc)[16 * MTP]) {
+        wino_mfma<P>(cw, cv, acc);
+        if constexpr (P + 1 < END) WinoMfmas<P + 1, END>::run(cw, cv, acc);
+    }
+};
+template <int I>
+struct WinoInOps {
+    static __device__ inline void run(const float (&d)[16], float (&t)[16], float (&v)[16]) {
+        wino_in_op<I>(d, t, v);
+        if constexpr (I + 1 < 32) WinoInOps<I + 1>::run(d, t, v);
     }
 };
 
-// k-step k of a pass, software-pipelined by hand (one wave per SIMD: nothing else hides latency):
-//   16 MTP MFMAs (transform points x M-tiles of the pass) on V(k) = cv and the weights cw, and between them the transform of
-//   patch d(k+1) = dt into nv, the LDS reads of patch d(k+2) into dl and the weight loads of k+1 into nw.
+// k-step k of a pass, software-pipelined by hand (one wave per SIMD: nothing else hides latency).
+// On gfx950 an fp32 MFMA and VALU work of the same wave do not overlap, and every MFMA -> VALU switch costs ~10 cycles
+// on top of the instruction itself (tools/ubench/mfma_bank.hip: MFMA/VALU alternating 46 cycles per MFMA, the same VALU
+// bunched 39, bare 32.5).  So a k-step is: WHEAD MFMAs | ONE bunch of everything else | the remaining MFMAs, where
+// the bunch = weight loads of step k+1 into nw, LDS reads of patch d(k+2) into dl, transform of patch d(k+1) = dt into nv.
+constexpr int WHEAD = 8;
 __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
                                  const float4* wnext, const float (&dt)[16], float (&nv)[16], float (&dl)[16],
                                  const float* xs, const int (&xo)[16], int kl, f32x4 (&acc)[16 * MTP]) {
-    float t[16];
-#ifndef AZ_K3_NOFENCE
-    // One wait per k-step instead of one per first use (each s_waitcnt between MFMAs costs ~4 cycles): these operands
-    // were requested a whole k-step ago; naming them all in one statement makes the compiler wait for them here, once.
+    // one wait for everything this step consumes (requested a whole step ago)
     wfence8(cw);
     wfence16(dt);
+    WinoMfmas<0, WHEAD>::run(cw, cv, acc);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef AZ_K3_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
+    wload4<4 * MTP>(nw, wnext);
 #endif
-    WinoSlices<0>::run(cw, cv, nw, wnext, dt, t, nv, dl, xs, xo, kl, acc);
+#ifdef AZ_K3_DBG_NOB    // diagnostic: no LDS patch reads (values made opaque so that the transform stays in the loop)
+#pragma unroll
+    for (int e = 0; e < 16; e++) asm volatile("" : "+v"(dl[e]));
+#else
+    wpatch(dl, xs, xo, kl);
+#endif
+#ifndef AZ_K3_DBG_NOXF  // diagnostic: no input transform
+    float t[16];
+    WinoInOps<0>::run(dt, t, nv);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    WinoMfmas<WHEAD, 16 * MTP>::run(cw, cv, acc);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // A^T M A for accumulator register r of the 16 point tiles -> the 2x2 outputs y[2a + b]

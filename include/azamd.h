@@ -83,7 +83,7 @@ typedef struct az_config {
     int64_t nodes_per_game; /* arena capacity in nodes; 0 = 1 + A*S*(reuse ? max_plies : 1)               */
     uint64_t game_id_base;  /* global id of slot 0 (multi-GPU: rank * n_games), keys the RNG streams      */
     int32_t n_cohorts;      /* AZ_EVAL_CNN: slot ranges searched on their own HIP streams so that one range's  */
-                            /* tree kernels overlap the other's CNN launch; 0 = auto (3 from 768 slots), max 4.   */
+                            /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 2048 slots, 3 from 768), max 4.   */
                             /* Results do not depend on it (games are independent).                            */
 } az_config;
 
