@@ -6,7 +6,7 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on, per GPU): Connect4 self-play,
 2048 concurrent games, 500 playouts per move, the reference's real CNN checkpoint evaluated on whole leaf batches
-by the fused fp32-MFMA kernel, Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for
+by the fused fp32-MFMA kernel (Winograd form), Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for
 10 plies then 1e-3, tree reuse, finished slots refilled with fresh games (Connect4/config.py:1-14).
 A "step" = one lockstep ply of every game slot: 500 x (select -> CNN leaf batch -> expand/backup), then move
 selection, env step, trajectory record, refill; finished trajectories are packed, all-gathered over RCCL (N>1) and
@@ -28,10 +28,15 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_LEAF = 41.62e6          # MAC = 2 flops, stem + 3 blocks + heads
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# K3 computes its 3x3 convolutions as Winograd F(2x2,3x3) products: the MFMA pipe EXECUTES 25.79 MFLOP per leaf
+# (15 740 v_mfma_f32_16x16x4_f32 per wave x 4 waves x 2 048 flop / 5 leaves per workgroup; profiles/r01_k3_pmc.txt), while
+# the roofline's `achieved` stays priced in ALGORITHMIC (direct-convolution) flops as SURVEY 8d defines it, so `frac` can
+# exceed the share of the MFMA pipe that is busy (reported next to it as executed_frac).
+EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 # HBM bytes per K3 launch of this workload from the PMC passes of tools/gpu_profile_round.sh (profiles/r01_k3_pmc.txt):
-# FETCH_SIZE 8037.4 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 35.0 KB.  It is the
-# 2.0 MB of weights fetched once per XCD L2 per launch; positions in and outputs out are 33 KB.
-K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8037.4 + 35.0) * 1024
+# FETCH_SIZE 13536.3 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 21.6 KB.  It is the
+# 3.4 MB of Winograd-form weights fetched once per XCD L2 per launch; positions in and outputs out are ~25 KB.
+K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13536.3 + 21.6) * 1024
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -180,13 +185,17 @@ def main():
                        "leaf_evals": evals, "terminal_hits": term, "mean_tree_depth": depth,
                        "plies_stored_in_replay": sink.total_stored - stored0,
                        "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
-            "roofline": {"bound": "mfma", "kernel": "k_cnn_forward", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "k_cnn_forward_wino", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
                          "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
                          "launches": cnn["launches"], "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"],
                          "concurrent_cohorts": eng.n_cohorts,
-                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12},
+                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12,
+                         "algorithm": "Winograd F(2x2,3x3) for the 3x3 convolutions; achieved/frac in algorithmic "
+                                      "(direct-convolution) flops, 41.62 MFLOP per leaf",
+                         "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
+                         "executed_frac": achieved * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS},
             "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
