@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     const i64 s0 = (i64)blockIdx.x * WS;
     if (s0 >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, nn = lane & 15;
+    WTS(230);
 
     // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149) ----
     if (tid < WRS) {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     // ---- per-lane Winograd geometry: tile column -> patch cell offsets, output positions ----
     const int col_id = wave * 16 + nn;
     const bool cvalid = col_id < WCOLS;
-    int off[16];      // patch cell (i, j) -> index in an activation row, or the zero cell
+    int off[16];      // patch cell (i, j) -> BYTE offset in the activation image for k-step 0 (row g), or the zero cell's
     int opos[4];      // output (a, b) -> position index (the dump cell when !ovalid)
     bool ovalid[4];
     {
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
             for (int j = 0; j < 4; j++) {
                 const int rr = 2 * tr - 1 + i, cc = 2 * tc - 1 + j;
                 const bool ok = cvalid && rr >= 0 && rr < 6 && cc >= 0 && cc < 7;
-                off[4 * i + j] = ok ? (s * NPOS + rr * 7 + cc) : WZ;
+                off[4 * i + j] = (g * WRS + (ok ? (s * NPOS + rr * 7 + cc) : WZ)) * 4;
             }
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -394,6 +395,10 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     WTS(0);
     // ---- 3 residual blocks (Network.py:16-27) ----
     f32x4 acc2[8][4];                    // 1x1 output: [co2 tile][2x2 cell], register r <-> co2 = 16 mt2 + 4g + r
+    constexpr int WSTEP = 4 * MTP * 64;  // float4 per k-step of the weight stream
+    float4 wa[4 * MTP], wb[4 * MTP];     // weights of the current / next k-step
+    float da[16], db[16], va[16], vb[16];
+    wload4<4 * MTP>(wa, w.w3[0] + lane); // later blocks: requested before the previous block's epilogue
 #pragma unroll 1
     for (int blk = 0; blk < 3; blk++) {
 #pragma unroll
@@ -404,6 +409,11 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         }
         const float4* w3l = w.w3[blk] + lane;
         const float4* w1l = w.w1[blk] + lane;
+        // operands of k-steps 0 and 1 of the first pass; every later pass finds them requested during the previous
+        // pass's 1x1 section (the weights by the last k-step's look-ahead: the stream is contiguous across passes)
+        wpatch(da, xs, off, 0);
+        wpatch(db, xs, off, 4 * WRS);
+        wino_in(da, va);
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; pass++) {
             // -- Winograd-domain products for 16 MTP output channels: acc[16 mtl + p] (+ BN bias through point (1,1)) --
@@ -415,17 +425,10 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
                 const float4 b = *reinterpret_cast<const float4*>(w.b3[blk] + 16 * (pass * MTP + mtl) + 4 * g);
                 acc[16 * mtl + 5] = (f32x4){b.x, b.y, b.z, b.w};
             }
-            constexpr int WSTEP = 4 * MTP * 64;   // float4 per k-step of the weight stream
             const float4* wp = w3l + (size_t)pass * NKS * WSTEP;
-            float4 wa[4 * MTP], wb[4 * MTP];
-            float da[16], db[16], va[16], vb[16];
             int xo[16];                  // patch cell byte offsets, advanced four k-steps per trip
 #pragma unroll
-            for (int e = 0; e < 16; e++) xo[e] = (g * WRS + off[e]) * 4;
-            wload4<4 * MTP>(wa, wp);
-            wpatch(da, xs, xo, 0);
-            wpatch(db, xs, xo, 4 * WRS);
-            wino_in(da, va);
+            for (int e = 0; e < 16; e++) xo[e] = off[e];
             wmfma_enter();
             WTS(1 + (blk * 8 + pass) * 4 + 0);
             // look-ahead past the end (patches: two k-steps into the arrays behind xs; weights: one k-step into the next
@@ -442,6 +445,8 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
             }
             wmfma_drain(acc);
             WTS(1 + (blk * 8 + pass) * 4 + 1);
+            wpatch(da, xs, off, 0);          // next pass, k-steps 0 and 1 (the image does not change inside a block)
+            wpatch(db, xs, off, 4 * WRS);
             // -- output transform, SiLU, and the 1x1 product with these hidden channels as reduction index --
             float4 ua[2], ub[2];
             const float4* w1p = w1l + (size_t)(pass * MTP * 4) * 2 * 64;
@@ -470,7 +475,9 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
                     wmfma(acc2[7][c], cu[1].w, y[c]);
                 }
             }
+            wino_in(da, va);
         }
+        wload4<4 * MTP>(wa, w.w3[blk < 2 ? blk + 1 : 2] + lane);   // first weights of the next block
         wmfma_drain2(acc2);
         WTS(200 + blk * 3);
         __syncthreads();  // every wave has finished READING xs for this block's 3x3 convolution
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     // ---- Linear + log-softmax + predict(): wave w finishes samples w and w + 4 ----
     for (int s = wave; s < WS; s += 4)
         if (s0 + s < n) wino_finish(w, hb, s, lane, (i64)s_slot[s], s_player[s], logp, logv, probs, value);
+    WTS(231);
 }
 
 // ------------------------------------------------------------------------------------------------ host side

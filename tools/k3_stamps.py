@@ -42,6 +42,8 @@ def main():
         print("blk %d: barrier wait %d, epilogue %d" % (blk, t[201 + blk * 3] - t[200 + blk * 3],
                                                       t[202 + blk * 3] - t[201 + blk * 3]))
     print("blocks total %d cyc; first pass start - WTS0 = %d" % (t[220] - t[0], t[1] - t[0]))
+    print("kernel %d cyc: planes+stem+geometry %d, blocks %d, heads+linear+softmax %d" %
+          (t[231] - t[230], t[0] - t[230], t[220] - t[0], t[231] - t[220]))
     eng.close()
 
 
