@@ -131,3 +131,36 @@ def test_search_result_independent_of_cohorts(blob):
             for x, y in zip(ref, out):
                 for u, v in zip(x, y):
                     assert np.array_equal(u, v), C
+
+
+def test_invariants_full_size_c4_cnn(blob):
+    """BASELINE configs[2] shape (2048 Connect4 games x 500 playouts, real net, 4 cohorts) through size-independent
+    properties: root N = S, sum(child N) = S - 1; after prune_root(a) + S more playouts sum(child N) = n_a - 1 + S;
+    2048 identical games (eval mode, never-flip, first-max) give 2048 bit-identical trees wherever their leaves sit in
+    the CNN batches (workgroup, tile column, cohort); every leaf either reached the network or was terminal."""
+    from alphazero_amd.engine import SelfPlayEngine
+    Gn, S = 2048, 500
+    eng = SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="never",
+                         reuse_tree=True)
+    assert eng.n_cohorts == 4
+    eng.load_net(blob)
+    eng.search()
+    rc = eng.root_children()
+    assert (rc["root_visits"] == S).all() and (rc["n"] == 7).all()
+    assert (rc["visits"].sum(1) == S - 1).all()
+    for k in ("actions", "visits"):
+        assert (rc[k] == rc[k][0]).all(), k
+    assert (rc["q"].view(np.uint32) == rc["q"].view(np.uint32)[0]).all()
+    assert (rc["prior"].view(np.uint32) == rc["prior"].view(np.uint32)[0]).all()
+    a, pi = eng.choose_moves(temp=0.0)
+    assert (a == a[0]).all()
+    n_a = rc["visits"][0][list(rc["actions"][0]).index(int(a[0]))]
+    eng.advance(a)
+    eng.search()
+    rc2 = eng.root_children()
+    assert (rc2["root_visits"] == n_a + S).all()
+    assert (rc2["visits"].sum(1) == n_a - 1 + S).all()
+    assert (rc2["visits"] == rc2["visits"][0]).all()
+    st = eng.stats()
+    assert st["playouts"] == 2 * Gn * S and st["leaf_evals"] + st["terminal_hits"] == st["playouts"]
+    eng.close()
