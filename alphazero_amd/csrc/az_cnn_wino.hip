@@ -15,8 +15,9 @@
 //   * after a pass the output transform + BN bias + SiLU give h[16 co][col][2x2] in registers, and those registers ARE
 //     the B operands of the 1x1 convolution (k-step = accumulator register index r: lane group g holds co 4g + r),
 //     accumulated over the 8 passes into 32 tiles (128 registers): the hidden tensor of a block never touches LDS;
-//   * activations: LDS image [ci][sample*42 + pos] (stride 213, index 210 = a zero that out-of-board patch cells point to),
-//     written in place by the residual epilogue;
+//   * activations: LDS image [ci][cell], board rows padded to 9 cells [0, c0..c6, 0] so that a patch row is 4 contiguous
+//     cells with its out-of-board columns reading zeros, plus one row of zeros for the patch rows above / below the board
+//     (zero padding costs no instruction); 144 KB, written in place by the residual epilogue;
 //   * weights: pre-swizzled per-lane A operand streams, 16-byte loads, L2-resident (3.4 MB), the 4 waves of a workgroup
 //     walk the same stream so it is served by the CU's vector L1.
 #include <math.h>
@@ -35,9 +36,15 @@ constexpr int NPOS = 42;
 constexpr int WS = 5;             // samples per workgroup
 constexpr int WCOLS = WS * 12;    // tile columns per workgroup
 constexpr int WP = WS * NPOS;     // 210 positions
-constexpr int WRS = 213;          // LDS row stride (floats); [210..212] stay zero
-constexpr int WZ = WP;            // index of the zero cell in every row
-constexpr int WDUMP = WP + 1;     // cell of every row that takes the stores of outputs that do not exist
+// LDS activation image [ci][cell]: a board row is 9 cells [0, c0..c6, 0] (so columns -1, 7 and 8 = the next row's pad
+// are zeros and a patch row is 4 CONTIGUOUS cells), a sample 6 such rows, then a 10-cell row of zeros that the patch
+// rows above / below the board point to, then a dump cell for the outputs that do not exist.
+constexpr int WSR = 9;            // cells per board row
+constexpr int WSS = 6 * WSR;      // cells per sample
+constexpr int WZ = WS * WSS;      // 270: the zero row
+constexpr int WDUMP = WZ + 10;    // 280
+constexpr int WRS = 281;          // row stride (floats)
+__host__ __device__ constexpr int wcell(int s, int row, int col) { return s * WSS + row * WSR + col + 1; }
 constexpr int NKS = HD / 4;       // k-steps of 4 input channels
 constexpr int MTP = 2;            // M-tiles (16 output channels each) per pass
 constexpr int NPASS = 8 / MTP;
@@ -110,9 +117,12 @@ __device__ inline void wload4(float4 (&w)[U], const float4* p) {
 __device__ inline float wlds(const float* xs, int byte_off, int koff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xs) + byte_off + koff * 4);
 }
-__device__ inline void wpatch(float (&d)[16], const float* xs, const int (&xo)[16], int koff) {
+// xo[i] = byte offset of patch row i (4 contiguous cells)
+__device__ inline void wpatch(float (&d)[16], const float* xs, const int (&xo)[4], int koff) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) d[e] = wlds(xs, xo[e], koff);
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[4 * i + j] = wlds(xs, xo[i], koff + j);
 }
 
 // Winograd-domain accumulate, D == C pinned in an accumulation register.  As a builtin, the register allocator (AGPR
@@ -189,10 +199,13 @@ struct WinoInOps {
 // on top of the instruction itself (tools/ubench/mfma_bank.hip: MFMA/VALU alternating 46 cycles per MFMA, the same VALU
 // bunched 39, bare 32.5).  So a k-step is: WHEAD MFMAs | ONE bunch of everything else | the remaining MFMAs, where
 // the bunch = weight loads of step k+1 into nw, LDS reads of patch d(k+2) into dl, transform of patch d(k+1) = dt into nv.
-constexpr int WHEAD = 8;
+#ifndef AZ_K3_WHEAD
+#define AZ_K3_WHEAD 8
+#endif
+constexpr int WHEAD = AZ_K3_WHEAD;
 __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
                                  const float4* wnext, const float (&dt)[16], float (&nv)[16], float (&dl)[16],
-                                 const float* xs, const int (&xo)[16], int kl, f32x4 (&acc)[16 * MTP]) {
+                                 const float* xs, int (&xo)[4], f32x4 (&acc)[16 * MTP]) {
     // one wait for everything this step consumes (requested a whole step ago)
     wfence8(cw);
     wfence16(dt);
@@ -205,7 +218,12 @@ __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[
 #pragma unroll
     for (int e = 0; e < 16; e++) asm volatile("" : "+v"(dl[e]));
 #else
-    wpatch(dl, xs, xo, kl);
+    wpatch(dl, xs, xo, 0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        xo[e] += 4 * WRS * 4;
+        asm volatile("" : "+v"(xo[e]));   // keep the running address: re-associated to base + k * stride it needs 2 adds per row
+    }
 #endif
 #ifndef AZ_K3_DBG_NOXF  // diagnostic: no input transform
     float t[16];
@@ -242,12 +260,12 @@ __device__ inline void wino_finish(const CnnWDev& w, const float* hb, int s, int
     for (int k = 0; k < 3; k++) vl[k] = 0.f;
     for (int j = lane; j < 126; j += 64) {  // nn.Flatten of NCHW: index c*42 + h*7 + w
         const int c = j / NPOS, q = j % NPOS;
-        const float xv = hb[c * WRS + s * NPOS + q];
+        const float xv = hb[c * WRS + wcell(s, q / 7, q % 7)];
 #pragma unroll
         for (int a = 0; a < 7; a++) pl[a] += xv * w.plin_w[a * 126 + j];
     }
     if (lane < NPOS) {
-        const float xv = hb[3 * WRS + s * NPOS + lane];
+        const float xv = hb[3 * WRS + wcell(s, lane / 7, lane % 7)];
 #pragma unroll
         for (int k = 0; k < 3; k++) vl[k] += xv * w.vlin_w[k * NPOS + lane];
     }
@@ -304,10 +322,10 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
     WTS(230);
 
     // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149) ----
-    if (tid < WRS) {
+    if (tid < WP) {
         const int p = tid, s = p / NPOS, q = p % NPOS, row = q / 7, col = q % 7;
         float vx = 0.f, vo = 0.f, vt = 0.f;
-        if (p < WP && s0 + s < n) {
+        if (s0 + s < n) {
             const i64 slot = list ? (i64)list[s0 + s] : (s0 + s);
             const u64 w0 = states[slot * 2], w1 = states[slot * 2 + 1];
             const int bit = col * 7 + (5 - row);
@@ -324,10 +342,11 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         x0[2 * WRS + p] = vt;
         x0[3 * WRS + p] = 0.f;
     }
-    if (tid < HD) {
-        xs[tid * WRS + WZ] = 0.f;
-        xs[tid * WRS + WZ + 1] = 0.f;
-        xs[tid * WRS + WZ + 2] = 0.f;
+    // the cells nobody writes: 2 pads per board row, the zero row (and the dump cell); they stay zero for the whole kernel
+    for (int i = tid; i < HD * 71; i += 256) {
+        const int ch = i / 71, k = i % 71;
+        const int cell = k < 60 ? (k >> 1) * WSR + (k & 1) * (WSR - 1) : WZ + (k - 60);
+        xs[ch * WRS + cell] = 0.f;
     }
     __syncthreads();
 
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         const int pos = nt * 16 + nn;
         const bool pv = pos < WP;
         const int q = pos % NPOS, row = q / 7, col = q % 7;
+        const int cell = wcell(pos / NPOS, row, col);
         f32x4 a8[8];
 #pragma unroll
         for (int mt = 0; mt < 8; mt++) {
@@ -362,32 +382,28 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
 #pragma unroll
             for (int mt = 0; mt < 8; mt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) xs[(16 * mt + 4 * g + r) * WRS + pos] = wsilu(a8[mt][r]);
+                for (int r = 0; r < 4; r++) xs[(16 * mt + 4 * g + r) * WRS + cell] = wsilu(a8[mt][r]);
         }
     }
 
     // ---- per-lane Winograd geometry: tile column -> patch cell offsets, output positions ----
     const int col_id = wave * 16 + nn;
     const bool cvalid = col_id < WCOLS;
-    int off[16];      // patch cell (i, j) -> BYTE offset in the activation image for k-step 0 (row g), or the zero cell's
-    int opos[4];      // output (a, b) -> position index (the dump cell when !ovalid)
-    bool ovalid[4];
+    int off[4];       // patch row i -> BYTE offset of its 4 contiguous cells for k-step 0 (channel row g), or the zero row's
+    int opos[4];      // output (a, b) -> cell index, or the dump cell for an output that does not exist
     {
         const int s = col_id / 12, t = col_id % 12, tr = t / 4, tc = t % 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int rr = 2 * tr - 1 + i, cc = 2 * tc - 1 + j;
-                const bool ok = cvalid && rr >= 0 && rr < 6 && cc >= 0 && cc < 7;
-                off[4 * i + j] = (g * WRS + (ok ? (s * NPOS + rr * 7 + cc) : WZ)) * 4;
-            }
+        for (int i = 0; i < 4; i++) {
+            const int rr = 2 * tr - 1 + i;
+            const bool ok = cvalid && rr >= 0 && rr < 6;
+            off[i] = (g * WRS + (ok ? wcell(s, rr, 2 * tc - 1) : WZ)) * 4;   // columns -1, 7, 8 are the rows' zero pads
+        }
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-                ovalid[2 * a + b] = cvalid && (2 * tc + b < 7);
-                opos[2 * a + b] = ovalid[2 * a + b] ? (s * NPOS + (2 * tr + a) * 7 + 2 * tc + b) : WDUMP;
+                opos[2 * a + b] = (cvalid && (2 * tc + b < 7)) ? wcell(s, 2 * tr + a, 2 * tc + b) : WDUMP;
             }
     }
     __syncthreads();
@@ -426,22 +442,20 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
                 acc[16 * mtl + 5] = (f32x4){b.x, b.y, b.z, b.w};
             }
             const float4* wp = w3l + (size_t)pass * NKS * WSTEP;
-            int xo[16];                  // patch cell byte offsets, advanced four k-steps per trip
-#pragma unroll
-            for (int e = 0; e < 16; e++) xo[e] = off[e];
+            int xo[4];                   // patch row byte offsets of the look-ahead (k-step + 2), advanced every k-step:
+#pragma unroll                           // ds_read2_b32 has 8-bit offsets, the k-step stride cannot be an immediate
+            for (int e = 0; e < 4; e++) xo[e] = off[e] + 8 * WRS * 4;
             wmfma_enter();
             WTS(1 + (blk * 8 + pass) * 4 + 0);
             // look-ahead past the end (patches: two k-steps into the arrays behind xs; weights: one k-step into the next
             // pass / the allocation's slack) is loaded and never used: unconditional loads keep addressing on immediates.
 #pragma unroll 1
             for (int ks = 0; ks < NKS; ks += 4) {
-                wino_step(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, 8 * WRS, acc);
-                wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, 12 * WRS, acc);
-                wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, 16 * WRS, acc);
+                wino_step(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, acc);
+                wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, acc);
+                wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, acc);
                 wp += 4 * WSTEP;
-                wino_step(wb, vb, wa, wp, da, va, db, xs, xo, 20 * WRS, acc);
-#pragma unroll
-                for (int e = 0; e < 16; e++) xo[e] += 16 * WRS * 4;
+                wino_step(wb, vb, wa, wp, da, va, db, xs, xo, acc);
             }
             wmfma_drain(acc);
             WTS(1 + (blk * 8 + pass) * 4 + 1);
@@ -527,10 +541,12 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         if (g == 0) {  // rows 0..3 live in registers 0..3 of lanes 0..15
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                if (ovalid[c]) {
+            {   // outputs that do not exist land in the rows' dump cells
+                int op = opos[c];
+                asm volatile("" : "+v"(op));   // computed here, not hoisted to the kernel's start and carried in registers
 #pragma unroll
-                    for (int r = 0; r < 4; r++) hb[r * WRS + opos[c]] = wsilu(hacc[c][r] + w.b_head[r]);
-                }
+                for (int r = 0; r < 4; r++) hb[r * WRS + op] = wsilu(hacc[c][r] + w.b_head[r]);
+            }
         }
     }
     __syncthreads();
