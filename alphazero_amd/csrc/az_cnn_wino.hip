@@ -120,9 +120,14 @@ __device__ inline float wlds(const float* xs, int byte_off, int koff) {
 // xo[i] = byte offset of patch row i (4 contiguous cells)
 __device__ inline void wpatch(float (&d)[16], const float* xs, const int (&xo)[4], int koff) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) d[4 * i + j] = wlds(xs, xo[i], koff + j);
+    for (int i = 0; i < 4; i++) {
+        // one 16-byte LDS read per patch row at 4-byte alignment (unaligned DS access mode of the HSA runtime)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xs) + xo[i] + koff * 4);
+        d[4 * i + 0] = v[0];
+        d[4 * i + 1] = v[1];
+        d[4 * i + 2] = v[2];
+        d[4 * i + 3] = v[3];
+    }
 }
 
 // Winograd-domain accumulate, D == C pinned in an accumulation register.  As a builtin, the register allocator (AGPR
@@ -205,7 +210,7 @@ struct WinoInOps {
 constexpr int WHEAD = AZ_K3_WHEAD;
 __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
                                  const float4* wnext, const float (&dt)[16], float (&nv)[16], float (&dl)[16],
-                                 const float* xs, int (&xo)[4], f32x4 (&acc)[16 * MTP]) {
+                                 const float* xs, const int (&xo)[4], int kl, f32x4 (&acc)[16 * MTP]) {
     // one wait for everything this step consumes (requested a whole step ago)
     wfence8(cw);
     wfence16(dt);
@@ -218,12 +223,7 @@ __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[
 #pragma unroll
     for (int e = 0; e < 16; e++) asm volatile("" : "+v"(dl[e]));
 #else
-    wpatch(dl, xs, xo, 0);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        xo[e] += 4 * WRS * 4;
-        asm volatile("" : "+v"(xo[e]));   // keep the running address: re-associated to base + k * stride it needs 2 adds per row
-    }
+    wpatch(dl, xs, xo, kl);
 #endif
 #ifndef AZ_K3_DBG_NOXF  // diagnostic: no input transform
     float t[16];
@@ -442,20 +442,22 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
                 acc[16 * mtl + 5] = (f32x4){b.x, b.y, b.z, b.w};
             }
             const float4* wp = w3l + (size_t)pass * NKS * WSTEP;
-            int xo[4];                   // patch row byte offsets of the look-ahead (k-step + 2), advanced every k-step:
-#pragma unroll                           // ds_read2_b32 has 8-bit offsets, the k-step stride cannot be an immediate
-            for (int e = 0; e < 4; e++) xo[e] = off[e] + 8 * WRS * 4;
+            int xo[4];                   // patch row byte offsets, advanced four k-steps per trip
+#pragma unroll
+            for (int e = 0; e < 4; e++) xo[e] = off[e];
             wmfma_enter();
             WTS(1 + (blk * 8 + pass) * 4 + 0);
             // look-ahead past the end (patches: two k-steps into the arrays behind xs; weights: one k-step into the next
             // pass / the allocation's slack) is loaded and never used: unconditional loads keep addressing on immediates.
 #pragma unroll 1
             for (int ks = 0; ks < NKS; ks += 4) {
-                wino_step(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, acc);
-                wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, acc);
-                wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, acc);
+                wino_step(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, 8 * WRS, acc);
+                wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, 12 * WRS, acc);
+                wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, 16 * WRS, acc);
                 wp += 4 * WSTEP;
-                wino_step(wb, vb, wa, wp, da, va, db, xs, xo, acc);
+                wino_step(wb, vb, wa, wp, da, va, db, xs, xo, 20 * WRS, acc);
+#pragma unroll
+                for (int e = 0; e < 4; e++) xo[e] += 16 * WRS * 4;
             }
             wmfma_drain(acc);
             WTS(1 + (blk * 8 + pass) * 4 + 1);
