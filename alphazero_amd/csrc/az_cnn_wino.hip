@@ -138,6 +138,10 @@ __device__ inline void wpatch(float (&d)[16], const float* xs, const int (&xo)[4
 __device__ inline void wmfma(f32x4& c, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// first k-step of a pass: D = A*B + 0, so that the 30 tiles without a bias need no initialisation at all
+__device__ inline void wmfma0(f32x4& c, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
 __device__ inline void wmfma_enter() { asm volatile("s_nop 3"); }
 // 8-pass MFMA result -> any non-MFMA reader: 12 wait states.  Tiles 0..11 are at least 4 MFMAs (128 cycles) old here.
 __device__ inline void wmfma_drain(f32x4 (&acc)[16 * MTP]) {
@@ -178,17 +182,18 @@ __device__ inline void wino_in_op(const float (&d)[16], float (&t)[16], float (&
 }
 
 // MFMA number P of a k-step: M-tile P / 16 of the pass, transform point P % 16.
-template <int P>
+template <int P, bool FIRST>
 __device__ inline void wino_mfma(const float4 (&cw)[4 * MTP], const float (&cv)[16], f32x4 (&acc)[16 * MTP]) {
     constexpr int Q = P >> 2;
     const float a = (P & 3) == 0 ? cw[Q].x : (P & 3) == 1 ? cw[Q].y : (P & 3) == 2 ? cw[Q].z : cw[Q].w;
-    wmfma(acc[P], a, cv[P & 15]);
+    if constexpr (FIRST && (P & 15) != 5) wmfma0(acc[P], a, cv[P & 15]);   // tile 5 = point (1,1) starts from the BN bias
+    else wmfma(acc[P], a, cv[P & 15]);
 }
-template <int P, int END>
+template <int P, int END, bool FIRST>
 struct WinoMfmas {
     static __device__ inline void run(const float4 (&cw)[4 * MTP], const float (&cv)[16], f32x4 (&acc)[16 * MTP]) {
-        wino_mfma<P>(cw, cv, acc);
-        if constexpr (P + 1 < END) WinoMfmas<P + 1, END>::run(cw, cv, acc);
+        wino_mfma<P, FIRST>(cw, cv, acc);
+        if constexpr (P + 1 < END) WinoMfmas<P + 1, END, FIRST>::run(cw, cv, acc);
     }
 };
 template <int I>
@@ -208,13 +213,14 @@ struct WinoInOps {
 #define AZ_K3_WHEAD 8
 #endif
 constexpr int WHEAD = AZ_K3_WHEAD;
+template <bool FIRST = false>
 __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[16], float4 (&nw)[4 * MTP],
                                  const float4* wnext, const float (&dt)[16], float (&nv)[16], float (&dl)[16],
                                  const float* xs, const int (&xo)[4], int kl, f32x4 (&acc)[16 * MTP]) {
     // one wait for everything this step consumes (requested a whole step ago)
     wfence8(cw);
     wfence16(dt);
-    WinoMfmas<0, WHEAD>::run(cw, cv, acc);
+    WinoMfmas<0, WHEAD, FIRST>::run(cw, cv, acc);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef AZ_K3_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
     wload4<4 * MTP>(nw, wnext);
@@ -230,7 +236,7 @@ __device__ inline void wino_step(const float4 (&cw)[4 * MTP], const float (&cv)[
     WinoInOps<0>::run(dt, t, nv);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    WinoMfmas<WHEAD, 16 * MTP>::run(cw, cv, acc);
+    WinoMfmas<WHEAD, 16 * MTP, FIRST>::run(cw, cv, acc);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -348,9 +354,15 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         const int cell = k < 60 ? (k >> 1) * WSR + (k & 1) * (WSR - 1) : WZ + (k - 60);
         xs[ch * WRS + cell] = 0.f;
     }
-    __syncthreads();
 
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36), direct, columns = positions ----
+    float4 wst[18];   // the whole stem weight stream of this lane (requested before the first barrier, used by every tile)
+#pragma unroll
+    for (int i = 0; i < 18; i++) wst[i] = w.w_stem[i * 64 + lane];
+    float4 bst[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++) bst[mt] = *reinterpret_cast<const float4*>(w.b_stem + 16 * mt + 4 * g);
+    __syncthreads();
     for (int nt = wave; nt * 16 < WP; nt += 4) {
         const int pos = nt * 16 + nn;
         const bool pv = pos < WP;
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
         f32x4 a8[8];
 #pragma unroll
         for (int mt = 0; mt < 8; mt++) {
-            const float4 b = *reinterpret_cast<const float4*>(w.b_stem + 16 * mt + 4 * g);
+            const float4 b = bst[mt];
             a8[mt] = (f32x4){b.x, b.y, b.z, b.w};
         }
 #pragma unroll
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
             const int rr = row + dr, cc = col + dc;
             const bool ok = pv && rr >= 0 && rr < 6 && cc >= 0 && cc < 7;
             const float b = ok ? x0[g * WRS + pos + dr * 7 + dc] : 0.f;
-            const float4 wA = w.w_stem[(tap * 2 + 0) * 64 + lane], wB = w.w_stem[(tap * 2 + 1) * 64 + lane];
+            const float4 wA = wst[tap * 2 + 0], wB = wst[tap * 2 + 1];
             a8[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA.x, b, a8[0], 0, 0, 0);
             a8[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA.y, b, a8[1], 0, 0, 0);
             a8[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA.z, b, a8[2], 0, 0, 0);
@@ -433,9 +445,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; pass++) {
             // -- Winograd-domain products for 16 MTP output channels: acc[16 mtl + p] (+ BN bias through point (1,1)) --
-            f32x4 acc[16 * MTP];
-#pragma unroll
-            for (int p = 0; p < 16 * MTP; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[16 * MTP];   // written by the first k-step (wmfma0); only the bias tiles are initialised
 #pragma unroll
             for (int mtl = 0; mtl < MTP; mtl++) {
                 const float4 b = *reinterpret_cast<const float4*>(w.b3[blk] + 16 * (pass * MTP + mtl) + 4 * g);
@@ -449,8 +459,15 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_wino(CnnWDev w, i64 n_ho
             WTS(1 + (blk * 8 + pass) * 4 + 0);
             // look-ahead past the end (patches: two k-steps into the arrays behind xs; weights: one k-step into the next
             // pass / the allocation's slack) is loaded and never used: unconditional loads keep addressing on immediates.
+            wino_step<true>(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, 8 * WRS, acc);
+            wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, 12 * WRS, acc);
+            wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, 16 * WRS, acc);
+            wp += 4 * WSTEP;
+            wino_step(wb, vb, wa, wp, da, va, db, xs, xo, 20 * WRS, acc);
+#pragma unroll
+            for (int e = 0; e < 4; e++) xo[e] += 16 * WRS * 4;
 #pragma unroll 1
-            for (int ks = 0; ks < NKS; ks += 4) {
+            for (int ks = 4; ks < NKS; ks += 4) {
                 wino_step(wa, va, wb, wp + WSTEP, db, vb, da, xs, xo, 8 * WRS, acc);
                 wino_step(wb, vb, wa, wp + 2 * WSTEP, da, va, db, xs, xo, 12 * WRS, acc);
                 wino_step(wa, va, wb, wp + 3 * WSTEP, db, vb, da, xs, xo, 16 * WRS, acc);
