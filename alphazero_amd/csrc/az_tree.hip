@@ -417,9 +417,12 @@ __device__ inline void backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 // mode bit0: backup of the evaluated playout, bit1: select of the next one.  Between two evaluator launches the
 // engine issues ONE kernel that finishes playout i and walks playout i+1 (same group, same wave, so the walk sees the
 // statistics the backup has just written), instead of a backup launch followed by a select launch.
-template <class G>
-__global__ __launch_bounds__(256) void k_tree_step(Dev d, int mode, u32* clear_count) {
-    constexpr int LG = G::LG, GPB = 256 / LG;
+// BS: workgroup size.  Under the CNN workload every CU is held by a K3 workgroup that owns its whole register file, so a
+// tree-step workgroup waits for a CU to come free: fewer, larger workgroups (512 threads = 64 Connect4 games) need
+// fewer CUs and start sooner.
+template <class G, int BS>
+__global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count) {
+    constexpr int LG = G::LG, GPB = BS / LG;
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ float s_Q[GPB][G::MAXD];
@@ -709,11 +712,14 @@ int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
     return AZ_OK;
 }
 
+#ifndef AZ_TREE_STEP_BS
+#define AZ_TREE_STEP_BS 512
+#endif
 // mode 2 = select, 1 = backup, 3 = backup of playout i then select of playout i+1
 static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
-        constexpr int gpb = 256 / GT::LG;
-        k_tree_step<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count);
+        constexpr int BS = AZ_TREE_STEP_BS, gpb = BS / GT::LG;
+        k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
