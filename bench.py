@@ -34,9 +34,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 d
 # exceed the share of the MFMA pipe that is busy (reported next to it as executed_frac).
 EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 # HBM bytes per K3 launch of this workload from the PMC passes of tools/gpu_profile_round.sh (profiles/r01_k3_pmc.txt):
-# FETCH_SIZE 13542.8 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 21.6 KB.  It is the
+# FETCH_SIZE 13544.8 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 33.4 KB.  It is the
 # 3.4 MB of Winograd-form weights fetched once per XCD L2 per launch; positions in and outputs out are ~25 KB.
-K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13542.8 + 21.6) * 1024
+K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
