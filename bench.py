@@ -40,18 +40,13 @@ K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
-def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0):
-    """The CPU oracle (C port of the reference algorithm: sequential single-game MCTS, one batch-1 fp32 CNN forward
-    per playout) timed on this box's host, one thread, on a bounded sample: whole moves of one game until the
-    budget is used."""
-    from oracle import oracle as orc
-    net = orc.CNN(blob)
+def _cpu_moves(orc, net, n_playout, budget_s, seed):
+    """whole moves of Connect4 self-play games with the CPU oracle until the budget is used -> (moves, games, playouts)"""
     t = orc.MCTS("Connect4", c_init=1.25, n_playout=n_playout, eval_kind=orc.EVAL_CNN, net=net)
     env = orc.Env("Connect4")
     t0 = time.perf_counter()
-    moves = 0
-    rng = np.random.default_rng(0)
-    ply = games = 0
+    rng = np.random.default_rng(seed)
+    moves = ply = games = 0
     while time.perf_counter() - t0 < budget_s:
         if env.done():  # next game of the sample
             env = orc.Env("Connect4")
@@ -66,13 +61,39 @@ def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0):
         env.step(a)
         moves += 1
         ply += 1
+    return moves, games + 1, t.stat_playouts
+
+
+def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=8.0):
+    """The CPU oracle (C port of the reference algorithm: sequential single-game MCTS, one batch-1 fp32 CNN forward
+    per playout) timed on this box's host on a bounded sample: whole moves of self-play games until the budget is used.
+    `value` is ONE thread (what the reference's single-threaded Python loop maps to); `all_cores` runs one
+    independent game sequence per core of this job's CPU share (the C calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    net = orc.CNN(blob)
+    t0 = time.perf_counter()
+    moves, games, sims = _cpu_moves(orc, net, n_playout, budget_s, 0)
     dt = time.perf_counter() - t0
-    sims = t.stat_playouts
     sims_s = sims / dt
-    return dict(value=sims_s / (n_playout * mean_len), unit="games/s", cores=1, kind="port",
-                sims_per_s=sims_s, sample="%d moves x %d playouts over %d Connect4 self-play game(s) (%.1f s), oracle/az_oracle*.c, "
-                "1 thread, no Dirichlet/flips; games/s = sims/s / (%d * %.1f plies)"
-                % (moves, n_playout, games + 1, dt, n_playout, mean_len))
+    out = dict(value=sims_s / (n_playout * mean_len), unit="games/s", cores=1, kind="port", sims_per_s=sims_s,
+               sample="%d moves x %d playouts over %d Connect4 self-play game(s) (%.1f s), oracle/az_oracle*.c, 1 thread, "
+                      "no Dirichlet/flips; games/s = sims/s / (%d * %.1f plies)" % (moves, n_playout, games, dt, n_playout, mean_len))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))   # the box's CPU share, not the machine
+    if multi_budget_s > 0 and cores > 1:
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(lambda i: _cpu_moves(orc, net, n_playout, multi_budget_s, 100 + i), range(cores)))
+        dtm = time.perf_counter() - t0
+        sims_m = sum(r[2] for r in res) / dtm
+        out["all_cores"] = dict(value=sims_m / (n_playout * mean_len), unit="games/s", cores=cores, sims_per_s=sims_m,
+                                sample="%d threads x independent game sequences, %d moves in %.1f s" %
+                                       (cores, sum(r[0] for r in res), dtm))
+    return out
 
 
 def main():
@@ -201,6 +222,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, S, mean_len, args.cpu_budget)
             out["config"]["x_cpu_port_1core"] = games_s / out["cpu_baseline"]["value"]
+            if "all_cores" in out["cpu_baseline"]:
+                out["config"]["x_cpu_port_all_cores"] = games_s / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
     eng.close()
     if world > 1:
