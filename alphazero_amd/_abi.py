@@ -76,6 +76,8 @@ SIGNATURES = {
     "az_set_game_target": (C.c_int, [_vp, _i64]),
     "az_selfplay": (_i64, [_vp, _i64, _dbl, _i32, _i64]),
     "az_selfplay_step": (C.c_int, [_vp, _dbl, _i32, _i32]),
+    "az_selfplay_rounds": (C.c_int, [_vp, _i32, _dbl, _i32, _i32]),
+    "az_selfplay_rolling": (_i64, [_vp, _i64, _dbl, _i32, _i64]),
     "az_traj_count": (C.c_int, [_vp, _P(_i64), _P(_i64)]),
     "az_traj_fetch": (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "az_traj_pack_dev": (_i64, [_vp, _i64, _vp, C.c_int]),

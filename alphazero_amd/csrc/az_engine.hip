@@ -98,6 +98,9 @@ struct az_engine {
     Cnn* net = nullptr;
     unsigned long long target = 0;
     int recording = 0;
+    // rolling self-play (az_selfplay_rounds): leaves are parked between calls; parity of the leaf counter in use
+    bool roll_started = false;
+    int roll_par = 0;
     // cohorts: the slots are cut into C ranges whose select -> CNN -> backup chains run on their own streams, so one
     // cohort's tree kernels and the ragged last round of its CNN launch overlap with the other cohort's CNN launch.
     int C = 1;
@@ -410,6 +413,7 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     A_(d.active, G);
     A_(d.flip_pos, G);
     A_(d.sim_ctr, G);
+    A_(d.move_sims, G);
     A_(d.game_id, G);
     A_(d.path_idx, G * gi.MAXD);
     A_(d.path_N, G * gi.MAXD);
@@ -681,6 +685,9 @@ static int ensure_out_cap(az_engine* e, i64 need) {
 int az_reset_games(az_engine* e) {
     AZ_CHECK_E(e);
     const Dev& d = e->d;
+    e->roll_started = false;
+    e->roll_par = 0;
+    AZ_HIP(hipMemsetAsync(d.eval_count, 0, 16 * AZ_MAX_COHORTS, e->stream));
     AZ_HIP(hipMemsetAsync(d.err, 0, sizeof(u32), e->stream));
     AZ_HIP(hipMemsetAsync(d.root_state, 0, (size_t)d.G * d.W * sizeof(u64), e->stream));
     AZ_TRY(launch_init_slots(d, e->cfg.game == AZ_GAME_NBTTT ? 1 : 0, e->cfg.game_id_base, e->stream));
@@ -694,6 +701,9 @@ int az_set_roots(az_engine* e, const uint64_t* states) {
     AZ_CHECK_E(e);
     if (!states) return AZ_ERR_ARG;
     const Dev& d = e->d;
+    e->roll_started = false;
+    e->roll_par = 0;
+    AZ_HIP(hipMemsetAsync(d.eval_count, 0, 16 * AZ_MAX_COHORTS, e->stream));
     AZ_HIP(hipMemcpyAsync(d.root_state, states, (size_t)d.G * d.W * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     AZ_TRY(launch_init_slots(d, 0, e->cfg.game_id_base, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
@@ -885,6 +895,103 @@ int az_selfplay_step(az_engine* e, double temp, int32_t first_n_steps, int32_t r
         AZ_TRY(launch_refill(d, e->p, target, e->cfg.game_id_base, e->stream));
     }
     return AZ_OK;
+}
+
+// Rolling self-play: n_rounds rounds of { CNN on every cohort's parked leaves ; tree step = finish those playouts, end the
+// plies that complete (move selection, env.step, prune_root, trajectory, refill) and walk every live game to its next
+// NON-terminal leaf }.  See az_tree.hip (Roll).  Leaves stay parked between calls.
+int az_selfplay_rounds(az_engine* e, int32_t n_rounds, double temp, int32_t first_n_steps, int32_t refill) {
+    AZ_CHECK_E(e);
+    const Dev& d = e->d;
+    if (d.evaluator != AZ_EVAL_CNN) {
+        set_error("az_selfplay_rounds: needs an AZ_EVAL_CNN engine (the synthetic evaluators run the fused search)");
+        return AZ_ERR_STATE;
+    }
+    if (!e->net) {
+        set_error("AZ_EVAL_CNN: call az_net_load first");
+        return AZ_ERR_NO_NET;
+    }
+    if (d.flip_mode == AZ_FLIP_STREAM && !d.flip_bits) {
+        set_error("AZ_FLIP_STREAM needs az_set_flip_stream first");
+        return AZ_ERR_STATE;
+    }
+    if (n_rounds <= 0) n_rounds = e->cfg.n_playout;
+    const unsigned long long target = refill ? (e->target ? e->target : ~0ull) : 0ull;
+    const int C = e->C, S = e->cfg.n_playout;
+    Dev dc[AZ_MAX_COHORTS][2];
+    hipStream_t cs[AZ_MAX_COHORTS];
+    for (int c = 0; c < C; c++) {
+        const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
+        for (int par = 0; par < 2; par++) {
+            dc[c][par] = d;
+            dc[c][par].g0 = (i32)lo;
+            dc[c][par].gn = (i32)(hi - lo);
+            dc[c][par].eval_count = d.eval_count + 4 * c + par;
+            dc[c][par].eval_list = d.eval_list + lo;
+        }
+        cs[c] = c == 0 ? e->stream : e->cstream[c];
+    }
+    if (C > 1) {
+        AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
+        for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
+    }
+    auto roll = [&](const Dev& dd, int mode, u32* stale, hipStream_t st) {
+        return launch_roll_step(dd, mode, stale, e->p, S, temp, first_n_steps, e->cfg.move_mode, e->cfg.reuse_tree, target,
+                                e->cfg.game_id_base, st);
+    };
+    if (!e->roll_started) {
+        for (int c = 0; c < C; c++) {
+            AZ_TRY(prof_begin(e, PROF_SELECT, cs[c]));
+            AZ_TRY(roll(dc[c][e->roll_par], 2, nullptr, cs[c]));
+            AZ_TRY(prof_end(e, cs[c]));
+        }
+        e->roll_started = true;
+    }
+    for (int s = 0; s < n_rounds; s++) {
+        const int par = e->roll_par;
+        for (int c = 0; c < C; c++) {
+            AZ_TRY(prof_begin(e, PROF_CNN, cs[c]));
+            AZ_TRY(cnn_eval_leaves(e->net, dc[c][par], cs[c]));
+            AZ_TRY(prof_end(e, cs[c]));
+            AZ_TRY(prof_begin(e, PROF_BACKUP, cs[c]));
+            AZ_TRY(roll(dc[c][par ^ 1], 3, dc[c][par].eval_count, cs[c]));
+            AZ_TRY(prof_end(e, cs[c]));
+        }
+        e->roll_par ^= 1;
+    }
+    if (C > 1) {
+        for (int c = 1; c < C; c++) {
+            AZ_HIP(hipEventRecord(e->ev_join[c], cs[c]));
+            AZ_HIP(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+        }
+    }
+    return AZ_OK;
+}
+
+int64_t az_selfplay_rolling(az_engine* e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_calls) {
+    AZ_CHECK_E(e);
+    if (n_games_target <= 0) return AZ_ERR_ARG;
+    AZ_TRY(az_reset_games(e));
+    unsigned long long zero = 0;
+    AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(e->p.out_games, &zero, 8, hipMemcpyHostToDevice));
+    AZ_TRY(ensure_out_cap(e, (n_games_target + e->d.G) * (i64)e->gi.MAX_PLIES));
+    e->target = (unsigned long long)n_games_target;
+    const Dev& d = e->d;
+    if (n_games_target < d.G) {  // fewer games than slots: park the surplus slots
+        std::vector<u8> act(d.G, 0);
+        for (i64 g = 0; g < n_games_target; g++) act[g] = 1;
+        AZ_HIP(hipMemcpy(d.active, act.data(), d.G, hipMemcpyHostToDevice));
+    }
+    unsigned long long finished = 0;
+    for (int64_t call = 0; max_calls <= 0 || call < max_calls; call++) {
+        AZ_TRY(az_selfplay_rounds(e, e->cfg.n_playout, temp, first_n_steps, 1));
+        int rc = az_engine_sync(e);
+        if (rc != AZ_OK) return rc;
+        AZ_HIP(hipMemcpy(&finished, e->p.out_games, 8, hipMemcpyDeviceToHost));
+        if (finished >= (unsigned long long)n_games_target) break;
+    }
+    return (int64_t)finished;
 }
 
 int az_set_game_target(az_engine* e, int64_t n_games_target) {

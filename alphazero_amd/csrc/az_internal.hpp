@@ -51,6 +51,7 @@ struct Dev {
     i64 flip_n;
     u32* flip_pos;        // [G]
     u64* sim_ctr;         // [G] playouts ever run in this slot's current game (RNG counter)
+    i32* move_sims;       // [G] rolling self-play: playouts done for the move being searched
     u64* game_id;         // [G]
     u64 rng_seed;
     float noise_alpha;    // <=0: off

@@ -11,109 +11,23 @@
 // One lane per game: these kernels run once per ply (the tree kernels run S times per ply).
 #include "az_internal.hpp"
 #include "az_play.hpp"
+#include "az_play_dev.hpp"
 
 namespace az {
-
-// numpy's float64 add-reduce order for a short contiguous array (n < 8: plain loop; else 8 partial sums).
-__device__ inline double np_sum(const double* a, int n) {
-    if (n < 8) {
-        double r = 0.0;
-        for (int i = 0; i < n; i++) r += a[i];
-        return r;
-    }
-    double res = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    for (int i = 8; i < n; i++) res += a[i];
-    return res;
-}
-
-__device__ inline double rng_uniform53(u64 seed, u64 gid, u64 ctr, u32 stream) {
-    u64 h = mix64(seed ^ mix64(gid * 0x9E3779B97F4A7C15ull + ctr) ^ ((u64)stream << 32));
-    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
-}
 
 template <class G>
 __global__ __launch_bounds__(256) void k_choose(Dev d, Play p, const double* temps, double temp_all, int first_n,
                                                int move_mode, i32* actions, float* pi) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
-    for (int a = 0; a < G::A; a++) pi[(i64)g * G::A + a] = 0.f;
     actions[g] = -1;
-    if (!d.active[g]) return;
-    const uint4* nodes = d.nodes + (i64)g * d.cap;
-    uint4 rr = nodes[d.root[g]];
-    int k = (int)link_nchild(rr.w);
-    u32 first = link_first(rr.w);
-    if (k == 0) return;
+    if (!d.active[g]) {
+        for (int a = 0; a < G::A; a++) pi[(i64)g * G::A + a] = 0.f;
+        return;
+    }
     double T = temps ? temps[g] : temp_all;
     if (!temps && first_n >= 0) T = (d.ply[g] >= first_n) ? 1e-3 : temp_all;  // game.py:41
-    int acts[G::A], vis[G::A];
-    double x[G::A], ex[G::A];
-    double t = T > 1e-8 ? T : 1e-8, mx = -INFINITY;
-    int maxv = 0;
-    for (int i = 0; i < k; i++) {
-        uint4 c = nodes[first + i];
-        acts[i] = (int)link_action(c.w);
-        vis[i] = (int)c.x;
-        if (vis[i] > maxv) maxv = vis[i];
-        x[i] = log((double)vis[i]) / t;  // np.log(visits) / max(temp, 1e-8)
-        if (x[i] > mx) mx = x[i];
-    }
-    for (int i = 0; i < k; i++) ex[i] = exp(x[i] - mx);
-    double s = np_sum(ex, k);
-    for (int i = 0; i < k; i++) pi[(i64)g * G::A + acts[i]] = (float)(ex[i] / s);  // action_probs[list(actions)] = visit_dist
-    int best = 0;
-    if (move_mode == AZ_MOVE_FIRST_MAX) {
-        if (T == 0) {
-            for (int i = 0; i < k; i++)
-                if (vis[i] == maxv) { best = i; break; }
-        } else {
-            double bd = -1.0;
-            for (int i = 0; i < k; i++) {
-                double dd = ex[i] / s;
-                if (dd > bd) { bd = dd; best = i; }
-            }
-        }
-    } else {
-        double u = rng_uniform53(d.rng_seed, d.game_id[g], (u64)d.ply[g], 7u);
-        if (T == 0) {  // player.py:106-108: uniform over the arg-max set
-            int cnt = 0;
-            for (int i = 0; i < k; i++) cnt += (vis[i] == maxv);
-            int pick = (int)(u * cnt);
-            if (pick >= cnt) pick = cnt - 1;
-            for (int i = 0; i < k; i++)
-                if (vis[i] == maxv) {
-                    if (pick == 0) { best = i; break; }
-                    pick--;
-                }
-        } else {  // np.random.choice(actions, p=visit_dist): inverse CDF
-            double acc = 0.0;
-            best = k - 1;
-            for (int i = 0; i < k; i++) {
-                acc += ex[i] / s;
-                if (u < acc) { best = i; break; }
-            }
-        }
-    }
-    actions[g] = acts[best];
-}
-
-template <class G>
-__device__ inline typename G::State opening_state(const Dev& d, u64 gid) {
-    typename G::State s = G::initial();
-    if constexpr (G::GAME == AZ_GAME_NBTTT) {  // NBTTT/env.py:15-23: two random opening plies
-        u64 h = mix64(d.rng_seed ^ mix64(gid + 0x5851F42D4C957F2Dull));
-        int board = (int)(h % 9), a1 = (int)((h >> 16) % 9);
-        s.w[3] = (u64)board;
-        G::step(s, a1);
-        u32 legal = G::legal(s) & ~(1u << board);
-        int m = __popc(legal), pick = (int)((h >> 32) % (u64)m);
-        for (int a = 0; a < 9; a++)
-            if ((legal >> a) & 1u) {
-                if (pick == 0) { G::step(s, a); break; }
-                pick--;
-            }
-    }
-    return s;
+    actions[g] = choose_game<G>(d, g, T, move_mode, pi + (i64)g * G::A, 1);
 }
 
 // env.step(action) + prune_root(action)/reset_player() + trajectory bookkeeping for every slot.
@@ -125,66 +39,7 @@ __global__ __launch_bounds__(256) void k_advance(Dev d, Play p, const i32* actio
     if (!d.active[g]) return;
     int a = actions[g];
     if (a < 0) return;
-    typename G::State s;
-    for (int i = 0; i < G::W; i++) s.w[i] = d.root_state[(i64)g * G::W + i];
-    int ply = d.ply[g];
-    if (record && ply < G::MAX_PLIES) {  // game.py:45-47: state, probs, current player BEFORE the move
-        i64 o = (i64)g * G::MAX_PLIES + ply;
-        for (int i = 0; i < G::W; i++) p.tj_state[o * G::W + i] = s.w[i];
-        for (int i = 0; i < G::A; i++) p.tj_pi[o * G::A + i] = pi[(i64)g * G::A + i];
-        p.tj_action[o] = (i8)a;
-        p.tj_player[o] = (i8)G::turn(s);
-    }
-    G::step(s, a);
-    for (int i = 0; i < G::W; i++) d.root_state[(i64)g * G::W + i] = s.w[i];
-    ply++;
-    d.ply[g] = ply;
-    uint4* nodes = d.nodes + (i64)g * d.cap;
-    bool kept = false;
-    if (reuse) {  // MCTS.py:131-133
-        uint4 rr = nodes[d.root[g]];
-        u32 k = link_nchild(rr.w), first = link_first(rr.w);
-        for (u32 i = 0; i < k; i++)
-            if ((int)link_action(nodes[first + i].w) == a) {
-                d.root[g] = first + i;
-                kept = true;
-                break;
-            }
-    }
-    if (!kept) {  // MCTS.py:134-135
-        nodes[0] = make_uint4(0u, 0u, __float_as_uint(1.0f), 0u);
-        d.root[g] = 0u;
-        d.n_alloc[g] = 1u;
-    }
-    int w = G::winner(s);
-    bool dn = (w != 0) || G::full(s);
-    d.winner[g] = (i8)w;
-    d.done[g] = dn ? 1 : 0;
-    atomicAdd(&d.stats[ST_PLIES], 1ull);
-    if (dn) {
-        d.active[g] = 0;
-        atomicAdd(&d.stats[ST_GAMES], 1ull);
-        if (record) {  // game.py:50-58: commit the finished game with z from each mover's perspective
-            int n = ply < G::MAX_PLIES ? ply : G::MAX_PLIES;
-            unsigned long long off = atomicAdd(p.out_count, (unsigned long long)n);
-            if ((i64)off + n <= p.out_cap) {
-                for (int j = 0; j < n; j++) {
-                    i64 o = (i64)g * G::MAX_PLIES + j, q = (i64)off + j;
-                    for (int i = 0; i < G::W; i++) p.out_state[q * G::W + i] = p.tj_state[o * G::W + i];
-                    for (int i = 0; i < G::A; i++) p.out_pi[q * G::A + i] = p.tj_pi[o * G::A + i];
-                    int pl = p.tj_player[o];
-                    p.out_z[q] = (w == 0) ? 0.f : ((pl == w) ? 1.f : -1.f);
-                    p.out_player[q] = (i8)pl;
-                    p.out_action[q] = p.tj_action[o];
-                    p.out_done[q] = (j == n - 1) ? 1 : 0;
-                    p.out_gid[q] = d.game_id[g];
-                }
-                atomicAdd(p.out_games, 1ull);
-            } else {
-                atomicOr(d.err, 4u);  // trajectory buffer full: game dropped
-            }
-        }
-    }
+    advance_game<G>(d, p, g, a, pi + (i64)g * G::A, 1, reuse, record);
 }
 
 // Restart finished slots with a fresh game while fewer than `target` games have been started.
@@ -192,22 +47,7 @@ template <class G>
 __global__ __launch_bounds__(256) void k_refill(Dev d, Play p, unsigned long long target, u64 gid_base) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
-    if (d.active[g] || !d.done[g]) return;
-    unsigned long long idx = atomicAdd(p.games_started, 1ull);
-    if (idx >= target) return;
-    u64 gid = gid_base + idx;
-    typename G::State s = opening_state<G>(d, gid);
-    for (int i = 0; i < G::W; i++) d.root_state[(i64)g * G::W + i] = s.w[i];
-    d.nodes[(i64)g * d.cap] = make_uint4(0u, 0u, __float_as_uint(1.0f), 0u);
-    d.root[g] = 0u;
-    d.n_alloc[g] = 1u;
-    d.ply[g] = 0;
-    d.sim_ctr[g] = 0;
-    d.game_id[g] = gid;
-    d.winner[g] = 0;
-    d.done[g] = 0;
-    d.active[g] = 1;
-    d.leaf_flags[g] = 0u;
+    refill_game<G>(d, p, g, target, gid_base);
 }
 
 // After az_set_roots / az_reset_games: derive status of every slot from its root position.
@@ -230,6 +70,7 @@ __global__ __launch_bounds__(256) void k_init_slots(Dev d, int use_openings, u64
     d.active[g] = dn ? 0 : 1;
     d.ply[g] = 0;
     d.sim_ctr[g] = 0;
+    d.move_sims[g] = 0;
     d.flip_pos[g] = 0;
     d.game_id[g] = gid;
     d.nodes[(i64)g * d.cap] = make_uint4(0u, 0u, __float_as_uint(1.0f), 0u);

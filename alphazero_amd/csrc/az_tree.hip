@@ -14,7 +14,10 @@
 // group lives inside one wavefront, so all tree reads/writes of a game are wavefront-ordered.
 //
 // This file must be compiled with -ffp-contract=off and correctly rounded f32 divide/sqrt (see Makefile).
+#include <string.h>
+
 #include "az_internal.hpp"
+#include "az_play_dev.hpp"
 
 namespace az {
 
@@ -368,10 +371,10 @@ __device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 }
 
 template <class G>
-__device__ inline void backup_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+__device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
     constexpr int LG = G::LG;
     const u32 flags = d.leaf_flags[g];
-    if (!(flags & 8u)) return;
+    if (!(flags & 8u)) return false;
     uint4* nodes = d.nodes + (i64)g * d.cap;
     Leaf lf;
     lf.depth = d.leaf_depth[g];
@@ -412,6 +415,103 @@ __device__ inline void backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
         atomicAdd(&d.stats[(flags & 1u) ? ST_TERMINAL : ST_EVALS], 1ull);
         atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
     }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Rolling self-play (az_selfplay_rounds): the games do not move in lockstep.  Every round each live game delivers
+// exactly ONE non-terminal leaf to the network: a playout that ends on a terminal node is finished on the spot and the
+// game walks again, and the playout that completes a move (the S-th) is followed at once, by the game's own lane group,
+// by move selection, env.step + prune_root, trajectory recording and -- when the game is over -- the slot's refill
+// (az_play_dev.hpp: the same functions the lockstep K4 kernels call).  Every game still runs its S playouts per move
+// one after the other with its own counter-keyed random streams, so each game's trajectory is the one lockstep
+// self-play produces; what changes is that leaf batches stay full although 20-60 % of late-game playouts are terminal.
+// ------------------------------------------------------------------------------------------------------------
+struct Roll {
+    int on;        // 0: lockstep tree step
+    int S;         // playouts per move
+    int first_n;   // game.py:41 temperature schedule (<0: temp for every ply)
+    int move_mode, reuse;
+    double temp;
+    unsigned long long target;   // games the refill may start in total (0: no refill)
+    u64 gid_base;
+    Play p;
+};
+
+// one playout of game g's current move has just been backed up: count it; at the S-th, end the ply.
+template <class G>
+__device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int gl) {
+    if (gl == 0) {
+        int ms = d.move_sims[g] + 1;
+        if (ms >= r.S) {
+            ms = 0;
+            float pi[G::A];
+            const double T = (r.first_n >= 0 && d.ply[g] >= r.first_n) ? 1e-3 : r.temp;   // game.py:41
+            const int a = choose_game<G>(d, g, T, r.move_mode, pi, 1);
+            if (a >= 0) advance_game<G>(d, r.p, g, a, pi, 1, r.reuse, 1);
+            if (r.target) refill_game<G>(d, r.p, g, r.target, r.gid_base);   // only acts on a finished slot
+        }
+        d.move_sims[g] = ms;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// select for rolling self-play: walk until a NON-terminal leaf is found (terminal playouts are completed in place)
+template <class G>
+__device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+    constexpr int LG = G::LG;
+    for (;;) {
+        if (!d.active[g]) {
+            if (gl == 0) d.leaf_flags[g] = 0u;
+            return;
+        }
+        uint4* nodes = d.nodes + (i64)g * d.cap;
+        typename G::State s = load_root_state<G>(d, g);
+        const u32 root = d.root[g];
+        uint4 rr = nodes[root];
+        Leaf lf = walk<G>(d, nodes, s, root, rr.x, as_f(rr.y), rr.w, gl, p_idx, p_N, p_Q);
+        typename G::State aug;
+        u32 fpos = d.flip_pos[g];
+        u64 ctr = d.sim_ctr[g];
+        leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (!(lf.flags & 1u)) {  // a leaf for the network: park the playout exactly like select_body
+            for (int dd = gl; dd <= lf.depth; dd += LG) {
+                d.path_idx[(i64)g * G::MAXD + dd] = p_idx[dd];
+                d.path_N[(i64)g * G::MAXD + dd] = p_N[dd];
+                d.path_Q[(i64)g * G::MAXD + dd] = p_Q[dd];
+            }
+            if (gl == 0) {
+#pragma unroll
+                for (int i = 0; i < G::W; i++) d.leaf_state[(i64)g * G::W + i] = aug.w[i];
+                d.leaf_depth[g] = lf.depth;
+                d.leaf_flags[g] = lf.flags | 8u;
+                d.leaf_tvalue[g] = lf.tvalue;
+                d.flip_pos[g] = fpos;
+                u32 pos = atomicAdd(d.eval_count, 1u);
+                d.eval_list[pos] = (u32)g;
+                atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
+            }
+            return;
+        }
+        // terminal leaf: MCTS.py:159-164 right away (no expansion, the constant value is backed up)
+        float probs[G::A];
+#pragma unroll
+        for (int a = 0; a < G::A; a++) probs[a] = 0.f;
+        u32 nalloc = d.n_alloc[g], rN = rr.x, rlink = rr.w, st_children = 0;
+        float rQ = as_f(rr.y);
+        finish<G>(d, g, nodes, aug, lf, probs, 0.f, gl, nalloc, root, rN, rQ, rlink, p_idx, p_N, p_Q, ctr, st_children);
+        if (gl == 0) {
+            d.sim_ctr[g] = ctr + 1;
+            d.flip_pos[g] = fpos;
+            d.leaf_flags[g] = 0u;
+            atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
+            atomicAdd(&d.stats[ST_PLAYOUTS], 1ull);
+            atomicAdd(&d.stats[ST_TERMINAL], 1ull);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        roll_playout_done<G>(d, r, g, gl);
+    }
 }
 
 // mode bit0: backup of the evaluated playout, bit1: select of the next one.  Between two evaluator launches the
@@ -421,7 +521,7 @@ __device__ inline void backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 // tree-step workgroup waits for a CU to come free: fewer, larger workgroups (512 threads = 64 Connect4 games) need
 // fewer CUs and start sooner.
 template <class G, int BS>
-__global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count) {
+__global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
     constexpr int LG = G::LG, GPB = BS / LG;
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
@@ -432,8 +532,13 @@ __global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_co
     const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
     const int g = d.g0 + blockIdx.x * GPB + grp;
     if (g >= d.g0 + d.gn) return;
-    if (mode & 1) backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
-    if (mode & 2) {
+    bool played = false;
+    if (mode & 1) played = backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    if (r.on) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (played) roll_playout_done<G>(d, r, g, gl);
+        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    } else if (mode & 2) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
     }
@@ -716,10 +821,13 @@ int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
 #define AZ_TREE_STEP_BS 512
 #endif
 // mode 2 = select, 1 = backup, 3 = backup of playout i then select of playout i+1
-static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_t st) {
+static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_t st, const Roll* roll = nullptr) {
+    Roll r;
+    memset(&r, 0, sizeof(r));
+    if (roll) r = *roll;
     AZ_DISPATCH_GAME(game_of(d), {
         constexpr int BS = AZ_TREE_STEP_BS, gpb = BS / GT::LG;
-        k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count);
+        k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count, r);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
@@ -735,6 +843,22 @@ int launch_backup(const Dev& d, hipStream_t st) { return launch_tree_step(d, 1, 
 // counters: `stale_count` is the one the evaluator has just consumed; it is cleared here for the round after next.
 int launch_backup_select(const Dev& d, u32* stale_count, hipStream_t st) {
     return launch_tree_step(d, 3, stale_count, st);
+}
+// rolling self-play: mode 2 = the very first selection, 3 = finish round i (+ ply ends) and select round i+1
+int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, int S, double temp, int first_n, int move_mode,
+                     int reuse, unsigned long long target, u64 gid_base, hipStream_t st) {
+    Roll r;
+    memset(&r, 0, sizeof(r));
+    r.on = 1;
+    r.S = S;
+    r.first_n = first_n;
+    r.move_mode = move_mode;
+    r.reuse = reuse;
+    r.temp = temp;
+    r.target = target;
+    r.gid_base = gid_base;
+    r.p = p;
+    return launch_tree_step(d, mode, stale_count, st, &r);
 }
 
 int launch_root_children(const Dev& d, i32* actions, i32* visits, float* q, float* prior, i32* nch, i32* rootN,

@@ -128,6 +128,15 @@ class SelfPlayEngine:
         check(int(r))
         return int(r)
 
+    def selfplay_rolling(self, n_games, temp=1.0, first_n_steps=10, max_calls=0):
+        """az_selfplay's contract on rolling rounds (no lockstep plies, full leaf batches): include/azamd.h"""
+        r = self.L.az_selfplay_rolling(self.h, int(n_games), float(temp), int(first_n_steps), int(max_calls))
+        check(int(r))
+        return int(r)
+
+    def selfplay_rounds(self, n_rounds=0, temp=1.0, first_n_steps=10, refill=True):
+        check(self.L.az_selfplay_rounds(self.h, int(n_rounds), float(temp), int(first_n_steps), 1 if refill else 0))
+
     def selfplay_step(self, temp=1.0, first_n_steps=10, refill=True):
         check(self.L.az_selfplay_step(self.h, float(temp), int(first_n_steps), 1 if refill else 0))
 

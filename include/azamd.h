@@ -182,6 +182,18 @@ int64_t az_selfplay(az_engine *e, int64_t n_games_target, double temp, int32_t f
 /* one lockstep ply for all live slots (search + choose + advance + record + refill); building block of
  * az_selfplay, exposed for bench.py (a "step").  Asynchronous. */
 int az_selfplay_step(az_engine *e, double temp, int32_t first_n_steps, int32_t refill);
+/* ROLLING self-play (no counterpart in the reference, which plays one game at a time; it is the batched form of
+ * Pipeline.data_collector's loop, Pipeline.py:53-63).  The games do not move in lockstep: every round each live game
+ * delivers exactly one NON-terminal leaf to the CNN (a playout that ends on a terminal node is finished on the spot and
+ * the game walks again), and the playout that completes a move is followed at once by move selection, env.step,
+ * prune_root, trajectory recording and the slot's refill, all inside the tree-step kernel.  Each game still runs its
+ * n_playout playouts per move one after the other with its own counter-keyed random streams, so every game's
+ * trajectory is the one az_selfplay / az_selfplay_step produce (tests/test_gpu_selfplay.py); leaf batches stay full.
+ * az_selfplay_rounds: n_rounds rounds (<= 0: cfg.n_playout), asynchronous; AZ_EVAL_CNN engines only; leaves stay parked
+ * between calls; do not mix with az_search / az_selfplay_step without az_reset_games / az_set_roots in between.
+ * az_selfplay_rolling: az_selfplay's contract (reset, play until n_games_target games have finished) on rolling rounds. */
+int az_selfplay_rounds(az_engine *e, int32_t n_rounds, double temp, int32_t first_n_steps, int32_t refill);
+int64_t az_selfplay_rolling(az_engine *e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_calls);
 /* total number of games az_selfplay_step's refill may start (0 = unlimited). */
 int az_set_game_target(az_engine *e, int64_t n_games_target);
 /* counts of finished games / recorded plies so far (synchronises). */

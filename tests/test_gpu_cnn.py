@@ -164,3 +164,45 @@ def test_invariants_full_size_c4_cnn(blob):
     st = eng.stats()
     assert st["playouts"] == 2 * Gn * S and st["leaf_evals"] + st["terminal_hits"] == st["playouts"]
     eng.close()
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.7])
+def test_rolling_selfplay_equals_lockstep(blob, noise):
+    """az_selfplay_rolling (no lockstep plies: terminal playouts finished in place, ply ends inside the tree step) must
+    produce, game id by game id, exactly the trajectories of the lockstep az_selfplay: every game runs its S playouts per
+    move sequentially on its own counter-keyed random streams in both, only the batching differs."""
+    from alphazero_amd.engine import SelfPlayEngine
+    Gn, S, N = 96, 40, 250
+
+    def run(rolling):
+        eng = SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
+                             reuse_tree=True, dirichlet_alpha=noise, rng_seed=5, move="sample", n_cohorts=3)
+        eng.load_net(blob)
+        n = eng.selfplay_rolling(N, temp=1.0, first_n_steps=6) if rolling else eng.selfplay(N, temp=1.0, first_n_steps=6)
+        t = eng.traj_fetch()
+        st = eng.stats()
+        eng.close()
+        return n, t, st
+
+    n1, t1, s1 = run(False)
+    n2, t2, s2 = run(True)
+    assert n1 == n2 == N
+
+    def by_game(t):
+        out = {}
+        order = np.argsort(t["game_id"], kind="stable")
+        for i in order:
+            out.setdefault(int(t["game_id"][i]), []).append(i)
+        return out
+
+    g1, g2 = by_game(t1), by_game(t2)
+    assert sorted(g1) == sorted(g2) == list(range(N))
+    for gid in g1:
+        i1, i2 = np.array(g1[gid]), np.array(g2[gid])
+        assert len(i1) == len(i2), gid
+        for k in ("states", "action", "player", "done"):
+            assert np.array_equal(t1[k][i1], t2[k][i2]), (gid, k)
+        assert np.array_equal(t1["pi"][i1].view(np.uint32), t2["pi"][i2].view(np.uint32)), gid
+        assert np.array_equal(t1["z"][i1], t2["z"][i2]), gid
+    for k in ("playouts", "leaf_evals", "terminal_hits", "plies", "games_finished", "levels", "children"):
+        assert s1[k] == s2[k], (k, s1[k], s2[k])
