@@ -28,61 +28,105 @@ __device__ inline double rng_uniform53(u64 seed, u64 gid, u64 ctr, u32 stream) {
 // softmax(ln N / max(T,1e-8)) as float32, returns the move (first-max or sampled) or -1 when the root has no children.
 template <class G>
 __device__ inline int choose_game(const Dev& d, int g, double T, int move_mode, float* pi, i64 pi_stride) {
-    for (int a = 0; a < G::A; a++) pi[a * pi_stride] = 0.f;
     const uint4* nodes = d.nodes + (i64)g * d.cap;
     uint4 rr = nodes[d.root[g]];
-    int k = (int)link_nchild(rr.w);
-    u32 first = link_first(rr.w);
-    if (k == 0) return -1;
+    const int k = (int)link_nchild(rr.w);
+    const u32 first = link_first(rr.w);
+    if (k == 0) {
+        for (int a = 0; a < G::A; a++) pi[a * pi_stride] = 0.f;
+        return -1;
+    }
+    // every loop runs over the static action count with an `i < k` predicate, so that the per-child arrays live in
+    // registers (this code also runs inside the tree step of rolling self-play)
     int acts[G::A], vis[G::A];
     double x[G::A], ex[G::A];
-    double t = T > 1e-8 ? T : 1e-8, mx = -INFINITY;
+    const double t = T > 1e-8 ? T : 1e-8;
+    double mx = -INFINITY;
     int maxv = 0;
-    for (int i = 0; i < k; i++) {
-        uint4 c = nodes[first + i];
-        acts[i] = (int)link_action(c.w);
-        vis[i] = (int)c.x;
-        if (vis[i] > maxv) maxv = vis[i];
-        x[i] = log((double)vis[i]) / t;  // np.log(visits) / max(temp, 1e-8)
-        if (x[i] > mx) mx = x[i];
+    uint4 c[G::A];
+#pragma unroll
+    for (int i = 0; i < G::A; i++) c[i] = nodes[first + (i < k ? i : 0)];
+#pragma unroll
+    for (int i = 0; i < G::A; i++) {
+        acts[i] = (int)link_action(c[i].w);
+        vis[i] = (int)c[i].x;
+        x[i] = 0.0;
+        if (i < k) {
+            if (vis[i] > maxv) maxv = vis[i];
+            x[i] = log((double)vis[i]) / t;  // np.log(visits) / max(temp, 1e-8)
+            if (x[i] > mx) mx = x[i];
+        }
     }
-    for (int i = 0; i < k; i++) ex[i] = exp(x[i] - mx);
-    double s = np_sum(ex, k);
-    for (int i = 0; i < k; i++) pi[acts[i] * pi_stride] = (float)(ex[i] / s);  // action_probs[list(actions)] = visit_dist
+#pragma unroll
+    for (int i = 0; i < G::A; i++) ex[i] = i < k ? exp(x[i] - mx) : 0.0;
+    double s;   // numpy's float64 add-reduce order (np_sum)
+    if (G::A < 8 || k < 8) {
+        s = 0.0;
+#pragma unroll
+        for (int i = 0; i < G::A; i++)
+            if (i < k) s += ex[i];
+    } else {
+        s = ((ex[0] + ex[1]) + (ex[2] + ex[3])) + ((ex[4] + ex[5 < G::A ? 5 : 0]) + (ex[6 < G::A ? 6 : 0] + ex[7 < G::A ? 7 : 0]));
+#pragma unroll
+        for (int i = 8; i < G::A; i++)
+            if (i < k) s += ex[i];
+    }
+    // action_probs[list(actions)] = visit_dist
+#pragma unroll
+    for (int a = 0; a < G::A; a++) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < G::A; i++)
+            if (i < k && acts[i] == a) v = (float)(ex[i] / s);
+        pi[a * pi_stride] = v;
+    }
     int best = 0;
     if (move_mode == AZ_MOVE_FIRST_MAX) {
         if (T == 0) {
-            for (int i = 0; i < k; i++)
-                if (vis[i] == maxv) { best = i; break; }
+            best = -1;
+#pragma unroll
+            for (int i = 0; i < G::A; i++)
+                if (best < 0 && i < k && vis[i] == maxv) best = i;
         } else {
             double bd = -1.0;
-            for (int i = 0; i < k; i++) {
+#pragma unroll
+            for (int i = 0; i < G::A; i++) {
                 double dd = ex[i] / s;
-                if (dd > bd) { bd = dd; best = i; }
+                if (i < k && dd > bd) { bd = dd; best = i; }
             }
         }
     } else {
         double u = rng_uniform53(d.rng_seed, d.game_id[g], (u64)d.ply[g], 7u);
         if (T == 0) {  // player.py:106-108: uniform over the arg-max set
             int cnt = 0;
-            for (int i = 0; i < k; i++) cnt += (vis[i] == maxv);
+#pragma unroll
+            for (int i = 0; i < G::A; i++) cnt += (i < k && vis[i] == maxv);
             int pick = (int)(u * cnt);
             if (pick >= cnt) pick = cnt - 1;
-            for (int i = 0; i < k; i++)
-                if (vis[i] == maxv) {
-                    if (pick == 0) { best = i; break; }
+            best = -1;
+#pragma unroll
+            for (int i = 0; i < G::A; i++)
+                if (best < 0 && i < k && vis[i] == maxv) {
+                    if (pick == 0) best = i;
                     pick--;
                 }
         } else {  // np.random.choice(actions, p=visit_dist): inverse CDF
             double acc = 0.0;
-            best = k - 1;
-            for (int i = 0; i < k; i++) {
-                acc += ex[i] / s;
-                if (u < acc) { best = i; break; }
-            }
+            best = -1;
+#pragma unroll
+            for (int i = 0; i < G::A; i++)
+                if (best < 0 && i < k) {
+                    acc += ex[i] / s;
+                    if (u < acc) best = i;
+                }
+            if (best < 0) best = k - 1;
         }
     }
-    return acts[best];
+    int act = acts[0];
+#pragma unroll
+    for (int i = 1; i < G::A; i++)
+        if (i == best) act = acts[i];
+    return act;
 }
 
 template <class G>

@@ -14,6 +14,7 @@
 // group lives inside one wavefront, so all tree reads/writes of a game are wavefront-ordered.
 //
 // This file must be compiled with -ffp-contract=off and correctly rounded f32 divide/sqrt (see Makefile).
+#include <stdlib.h>
 #include <string.h>
 
 #include "az_internal.hpp"
@@ -429,6 +430,7 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 // ------------------------------------------------------------------------------------------------------------
 struct Roll {
     int on;        // 0: lockstep tree step
+    int cap;       // terminal playouts a game may finish in place per round
     int S;         // playouts per move
     int first_n;   // game.py:41 temperature schedule (<0: temp for every ply)
     int move_mode, reuse;
@@ -460,11 +462,10 @@ __device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int
 template <class G>
 __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
     constexpr int LG = G::LG;
-    for (;;) {
-        if (!d.active[g]) {
-            if (gl == 0) d.leaf_flags[g] = 0u;
-            return;
-        }
+    // at most r.cap terminal playouts are finished in place per round: a game whose search has converged on a forced
+    // line ends ~all of its playouts on terminal nodes, and the launch lasts as long as its slowest game
+    for (int it = 0; it <= r.cap; it++) {
+        if (!d.active[g]) break;
         uint4* nodes = d.nodes + (i64)g * d.cap;
         typename G::State s = load_root_state<G>(d, g);
         const u32 root = d.root[g];
@@ -512,6 +513,7 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         roll_playout_done<G>(d, r, g, gl);
     }
+    if (gl == 0) d.leaf_flags[g] = 0u;   // no leaf for the network this round
 }
 
 // mode bit0: backup of the evaluated playout, bit1: select of the next one.  Between two evaluator launches the
@@ -850,6 +852,8 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     Roll r;
     memset(&r, 0, sizeof(r));
     r.on = 1;
+    static const char* cap_env = getenv("AZ_ROLL_CAP");   // tuning hook
+    r.cap = cap_env ? atoi(cap_env) : 3;
     r.S = S;
     r.first_n = first_n;
     r.move_mode = move_mode;

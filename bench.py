@@ -8,9 +8,12 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on, p
 2048 concurrent games, 500 playouts per move, the reference's real CNN checkpoint evaluated on whole leaf batches
 by the fused fp32-MFMA kernel (Winograd form), Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for
 10 plies then 1e-3, tree reuse, finished slots refilled with fresh games (Connect4/config.py:1-14).
-A "step" = one lockstep ply of every game slot: 500 x (select -> CNN leaf batch -> expand/backup), then move
-selection, env step, trajectory record, refill; finished trajectories are packed, all-gathered over RCCL (N>1) and
-expanded into ReplayBuffer-shaped tensors inside the timed region.
+A "step" = 500 rounds of every game slot, a round = CNN on the parked leaf batch -> tree step (expand/backup, and for
+the games whose move is complete: move selection, env step, trajectory record, refill; then the walk to the next leaf).
+In the default rolling mode (az_selfplay_rounds) the games advance individually and every round evaluates one
+non-terminal leaf per live game; --mode lockstep runs one ply of every slot per step (az_selfplay_step), the form the
+parity tests pin against the reference; both produce the same games (tests/test_gpu_cnn.py).  Finished trajectories
+are packed, all-gathered over RCCL (N>1) and expanded into ReplayBuffer-shaped tensors inside the timed region.
 
 value (games/s) = slot-plies per second / mean plies per finished game (steady-state estimator; the raw number of
 games that finished inside the timed window is reported as config.games_finished_in_window).
@@ -108,6 +111,9 @@ def main():
     ap.add_argument("--cohort", type=int, default=512, help="games of the untimed cohort that measures plies/game")
     ap.add_argument("--mean-plies", type=float, default=0.0, help="use this plies/game instead of playing a cohort")
     ap.add_argument("--cohorts", type=int, default=0, help="slot ranges searched on their own HIP streams (0 = engine default)")
+    ap.add_argument("--mode", choices=["rolling", "lockstep"], default="rolling",
+                    help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
+                         "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +144,10 @@ def main():
         torch.cuda.synchronize()
 
     def one_step():
-        eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
+        if args.mode == "rolling":
+            eng.selfplay_rounds(S, temp=1.0, first_n_steps=10, refill=True)
+        else:
+            eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
         eng.sync()
         recs = gather.gather()          # pack on device -> all_gather (RCCL) -> records of every rank
         sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
@@ -176,7 +185,7 @@ def main():
     else:
         cohort = min(G, args.cohort)
         eng.traj_fetch(clear=True)
-        n_done = eng.selfplay(cohort, temp=1.0, first_n_steps=10)
+        n_done = (eng.selfplay_rolling if args.mode == "rolling" else eng.selfplay)(cohort, temp=1.0, first_n_steps=10)
         cg, cp = eng.traj_count()
         assert cg == n_done == cohort, (cg, n_done, cohort)
         mean_len = cp / cg
@@ -201,7 +210,7 @@ def main():
                                    "AZ_Connect4_CNN_current weights, Dirichlet 0.7, random flips, tree reuse "
                                    "(BASELINE configs[2]%s)" % (G, S, "; trajectories all-gathered over RCCL into "
                                                                 "ReplayBuffer tensors" if world > 1 else ""),
-                       "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
+                       "mode": args.mode, "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
                        "games_finished_in_window": finished, "slot_plies_in_window": plies,
                        "leaf_evals": evals, "terminal_hits": term, "mean_tree_depth": depth,
                        "plies_stored_in_replay": sink.total_stored - stored0,
