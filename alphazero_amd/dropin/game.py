@@ -72,7 +72,7 @@ class Game:
                              rng_seed=rng_seed, move="sample", device=dev_index, game_id_base=rank << 40)
         try:
             eng.load_net(m.policy.export_flat())
-            eng.selfplay(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
+            eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
             recs = TrajectoryGatherer(eng, torch.device("cuda", dev_index)).gather()
         finally:
             eng.close()
@@ -82,7 +82,7 @@ class Game:
         return [int(x) for x in np.diff(np.concatenate([[-1], ends]))]
 
     def start_self_play_batch(self, player, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
-        """n_games self-play games in lockstep on the device with player's search settings (c_puct, n_playout, alpha,
+        """n_games self-play games at once on the device (rolling rounds, include/azamd.h) with player's search settings (c_puct, n_playout, alpha,
         train/eval mode) and network.  Returns a list of (winner, [6-tuples]) in completion order, each 6-tuple as
         game.py:58 builds it: (state (1,C,H,W) f32, pi (A,) f32, z, z, next_state, done)."""
         from alphazero_amd.engine import SelfPlayEngine, env_planes_batch, env_step_batch
@@ -97,7 +97,7 @@ class Game:
                              rng_seed=rng_seed, move="sample", device=getattr(m.policy, "device_index", 0))
         try:
             eng.load_net(m.policy.export_flat())
-            eng.selfplay(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
+            eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
             t = eng.traj_fetch(clear=True)
         finally:
             eng.close()
