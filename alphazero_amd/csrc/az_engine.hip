@@ -107,7 +107,8 @@ struct az_engine {
     hipStream_t cstream[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
     // live kernel timing with HIP events on the engine stream (az_set_profiling / az_get_profile)
-    int prof_on = 0;
+    int prof_on = 0;      // mask of the categories being timed
+    bool prof_skip = true;
     std::vector<hipEvent_t> prof_ev;   // pairs: [2i] start, [2i+1] stop
     std::vector<int> prof_cat;
     size_t prof_used = 0;
@@ -160,7 +161,8 @@ static int prof_harvest(az_engine* e) {
     return AZ_OK;
 }
 static int prof_begin(az_engine* e, int cat, hipStream_t st) {
-    if (!e->prof_on) return AZ_OK;
+    e->prof_skip = !(e->prof_on & (1 << cat));
+    if (e->prof_skip) return AZ_OK;
     if (e->prof_used * 2 >= e->prof_ev.size()) {
         int rc = prof_harvest(e);
         if (rc != AZ_OK) return rc;
@@ -170,7 +172,7 @@ static int prof_begin(az_engine* e, int cat, hipStream_t st) {
     return AZ_OK;
 }
 static int prof_end(az_engine* e, hipStream_t st) {
-    if (!e->prof_on) return AZ_OK;
+    if (e->prof_skip) return AZ_OK;
     AZ_HIP(hipEventRecord(e->prof_ev[2 * e->prof_used + 1], st));
     e->prof_used++;
     return AZ_OK;
@@ -597,12 +599,12 @@ int az_set_profiling(az_engine* e, int on) {
     AZ_HIP(hipStreamSynchronize(e->stream));
     AZ_TRY(prof_harvest(e));
     if (on && e->prof_ev.empty()) {
-        const size_t pairs = 16384;
+        const size_t pairs = 65536;   // a whole bench window of K3 launches: the read-back happens after the timed region
         e->prof_ev.resize(2 * pairs);
         e->prof_cat.resize(pairs);
         for (auto& ev : e->prof_ev) AZ_HIP(hipEventCreate(&ev));
     }
-    e->prof_on = on ? 1 : 0;
+    e->prof_on = on == 1 ? 0xF : (on == 2 ? (1 << PROF_CNN) : 0);   // category mask
     for (int i = 0; i < 4; i++) {
         e->prof_ms[i] = 0;
         e->prof_n[i] = 0;

@@ -189,7 +189,8 @@ class SelfPlayEngine:
         return {n: getattr(st, n) for n, _ in st._fields_}
 
     def set_profiling(self, on=True):
-        check(self.L.az_set_profiling(self.h, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel category, 2 the CNN launches only (include/azamd.h)"""
+        check(self.L.az_set_profiling(self.h, int(on)))
 
     def get_profile(self):
         ms = np.zeros(4, np.float64)

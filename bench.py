@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--cohort", type=int, default=512, help="games of the untimed cohort that measures plies/game")
     ap.add_argument("--mean-plies", type=float, default=0.0, help="use this plies/game instead of playing a cohort")
     ap.add_argument("--cohorts", type=int, default=0, help="slot ranges searched on their own HIP streams (0 = engine default)")
+    ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event kernel timing in the timed region")
+    ap.add_argument("--profile-all", action="store_true", help="HIP events around the tree-step launches too (kernel_time_ms)")
     ap.add_argument("--mode", choices=["rolling", "lockstep"], default="rolling",
                     help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
                          "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
@@ -155,7 +157,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     eng.reset_stats()
-    eng.set_profiling(True)
+    eng.set_profiling(0 if args.no_profile else (1 if args.profile_all else 2))   # 2: HIP events around the K3 launches only
     g0, _ = eng.traj_count()
     stored0 = sink.total_stored
     barrier()
@@ -199,7 +201,7 @@ def main():
         # GPU is the UNION of the launches' [start, stop] intervals (HIP events on the launch streams), not their sum.
         # achieved = algorithmic FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the
         # launches do not overlap, i.e. --cohorts 1).
-        achieved = FLOP_PER_LEAF * (evals / world) / (cnn["busy_ms"] * 1e-3) / 1e12
+        achieved = FLOP_PER_LEAF * (evals / world) / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
         depth = levels / max(playouts, 1)
         out = {
             "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
@@ -221,7 +223,7 @@ def main():
                          "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
                          "launches": cnn["launches"], "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"],
                          "concurrent_cohorts": eng.n_cohorts,
-                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (cnn_avg_ms * 1e-3) / 1e12,
+                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12,
                          "algorithm": "Winograd F(2x2,3x3) for the 3x3 convolutions; achieved/frac in algorithmic "
                                       "(direct-convolution) flops, 41.62 MFLOP per leaf",
                          "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
