@@ -112,18 +112,33 @@ __device__ inline float rng_gamma(float alpha, u64 seed, u64 gid, u64 ctr, u32 l
     return x;
 }
 
+// Lane exchange inside a group through DPP (data-parallel primitives: a VALU operand modifier, ~8 cycles) instead of
+// ds_bpermute (an LDS round trip, ~120 cycles on the walk's dependent chain).  STEP 0: lane ^ 1, 1: lane ^ 2 (quad
+// permutes), 2: mirror inside each half-row of 8 lanes, 3: mirror inside the row of 16.  After steps 0..log2(LG)-1 every
+// lane has met, directly or through a partner's running result, every other lane of its group of LG = 8 or 16 lanes.
+template <int STEP>
+__device__ inline u32 dpp_xchg(u32 v) {
+    constexpr int ctrl = STEP == 0 ? 0xB1 : STEP == 1 ? 0x4E : STEP == 2 ? 0x141 : 0x140;
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, true);
+}
+template <int STEP>
+__device__ inline void argmax_step(float& score, int& idx) {
+    const float os = as_f(dpp_xchg<STEP>(as_u(score)));
+    const int oi = (int)dpp_xchg<STEP>((u32)idx);
+    if (os > score || (os == score && oi < idx)) {
+        score = os;
+        idx = oi;
+    }
+}
+// first maximum over the group (ties -> lowest lane = insertion order, MCTS.py:79-80); every lane gets the result
 template <int LG>
 __device__ inline int group_argmax_first(float score, int gl) {
+    static_assert(LG == 8 || LG == 16, "lane groups of 8 or 16");
     int idx = gl;
-#pragma unroll
-    for (int m = LG / 2; m >= 1; m >>= 1) {
-        float os = __shfl_xor(score, m, LG);
-        int oi = __shfl_xor(idx, m, LG);
-        if (os > score || (os == score && oi < idx)) {
-            score = os;
-            idx = oi;
-        }
-    }
+    argmax_step<0>(score, idx);
+    argmax_step<1>(score, idx);
+    argmax_step<2>(score, idx);
+    if constexpr (LG == 16) argmax_step<3>(score, idx);
     return idx;
 }
 
@@ -558,18 +573,24 @@ __device__ inline double node_q64(const uint4& r) {
     return r.x ? __hiloint2double((int)r.z, (int)r.y) : 0.0;  // TreeNode.Q starts at 0 (MCTS.py:15)
 }
 
+template <int STEP>
+__device__ inline void argmax_step_f64(double& score, int& idx) {
+    const u32 lo = dpp_xchg<STEP>((u32)__double2loint(score)), hi = dpp_xchg<STEP>((u32)__double2hiint(score));
+    const double os = __hiloint2double((int)hi, (int)lo);
+    const int oi = (int)dpp_xchg<STEP>((u32)idx);
+    if (os > score || (os == score && oi < idx)) {
+        score = os;
+        idx = oi;
+    }
+}
 template <int LG>
 __device__ inline int group_argmax_first_f64(double score, int gl) {
+    static_assert(LG == 8 || LG == 16, "lane groups of 8 or 16");
     int idx = gl;
-#pragma unroll
-    for (int m = LG / 2; m >= 1; m >>= 1) {
-        double os = __shfl_xor(score, m, LG);
-        int oi = __shfl_xor(idx, m, LG);
-        if (os > score || (os == score && oi < idx)) {
-            score = os;
-            idx = oi;
-        }
-    }
+    argmax_step_f64<0>(score, idx);
+    argmax_step_f64<1>(score, idx);
+    argmax_step_f64<2>(score, idx);
+    if constexpr (LG == 16) argmax_step_f64<3>(score, idx);
     return idx;
 }
 
