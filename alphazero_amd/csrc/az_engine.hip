@@ -890,13 +890,9 @@ int az_selfplay_step(az_engine* e, double temp, int32_t first_n_steps, int32_t r
     AZ_CHECK_E(e);
     const Dev& d = e->d;
     AZ_TRY(az_search(e, e->cfg.n_playout));
-    AZ_TRY(launch_choose(d, e->p, nullptr, temp, first_n_steps, e->cfg.move_mode, e->d_actions, e->d_pi, e->stream));
-    AZ_TRY(launch_advance(d, e->p, e->d_actions, e->d_pi, e->cfg.reuse_tree, 1, e->stream));
-    if (refill) {
-        unsigned long long target = e->target ? e->target : ~0ull;
-        AZ_TRY(launch_refill(d, e->p, target, e->cfg.game_id_base, e->stream));
-    }
-    return AZ_OK;
+    const unsigned long long target = refill ? (e->target ? e->target : ~0ull) : 0ull;
+    return launch_ply_end(d, e->p, temp, first_n_steps, e->cfg.move_mode, e->cfg.reuse_tree, target, e->cfg.game_id_base,
+                          e->stream);
 }
 
 // Rolling self-play: n_rounds rounds of { CNN on every cohort's parked leaves ; tree step = finish those playouts, end the

@@ -50,6 +50,21 @@ __global__ __launch_bounds__(256) void k_refill(Dev d, Play p, unsigned long lon
     refill_game<G>(d, p, g, target, gid_base);
 }
 
+// One whole ply end per slot: k_choose + k_advance(record) + k_refill in a single launch (az_selfplay_step).
+template <class G>
+__global__ __launch_bounds__(256) void k_ply_end(Dev d, Play p, double temp_all, int first_n, int move_mode, int reuse,
+                                                unsigned long long target, u64 gid_base) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    if (d.active[g]) {
+        float pi[G::A];
+        const double T = (first_n >= 0 && d.ply[g] >= first_n) ? 1e-3 : temp_all;  // game.py:41
+        const int a = choose_game<G>(d, g, T, move_mode, pi, 1);
+        if (a >= 0) advance_game<G>(d, p, g, a, pi, 1, reuse, 1);
+    }
+    if (target) refill_game<G>(d, p, g, target, gid_base);
+}
+
 // After az_set_roots / az_reset_games: derive status of every slot from its root position.
 template <class G>
 __global__ __launch_bounds__(256) void k_init_slots(Dev d, int use_openings, u64 gid_base) {
@@ -97,6 +112,13 @@ int launch_choose(const Dev& d, const Play& p, const double* temps, double temp_
 int launch_advance(const Dev& d, const Play& p, const i32* actions, const float* pi, int reuse, int record,
                    hipStream_t st) {
     AZ_DISPATCH_GAME(d.game, k_advance<GT><<<dim3((d.G + 255) / 256), dim3(256), 0, st>>>(d, p, actions, pi, reuse, record));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+int launch_ply_end(const Dev& d, const Play& p, double temp_all, int first_n, int move_mode, int reuse,
+                   unsigned long long target, u64 gid_base, hipStream_t st) {
+    AZ_DISPATCH_GAME(d.game, k_ply_end<GT><<<dim3((d.G + 255) / 256), dim3(256), 0, st>>>(d, p, temp_all, first_n, move_mode, reuse, target, gid_base));
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }

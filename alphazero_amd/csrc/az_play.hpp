@@ -29,6 +29,9 @@ int launch_choose(const Dev& d, const Play& p, const double* temps, double temp_
 int launch_advance(const Dev& d, const Play& p, const i32* actions, const float* pi, int reuse, int record,
                    hipStream_t st);
 int launch_refill(const Dev& d, const Play& p, unsigned long long target, u64 gid_base, hipStream_t st);
+// choose + advance (recording) + refill (target != 0) of every slot in one launch
+int launch_ply_end(const Dev& d, const Play& p, double temp_all, int first_n, int move_mode, int reuse,
+                   unsigned long long target, u64 gid_base, hipStream_t st);
 int launch_init_slots(const Dev& d, int use_openings, u64 gid_base, hipStream_t st);
 // rolling self-play tree step (az_tree.hip): mode 2 = the very first selection, 3 = finish round i (with the ply ends that
 // fall into it) and select round i+1; stale_count = the leaf counter the evaluator has just consumed (cleared here).
