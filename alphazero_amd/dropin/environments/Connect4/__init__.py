@@ -1,10 +1,17 @@
 from .config import training_config, network_config, env_config
 from ..bitboard_env import Connect4Env as Env
 from ..network import CNN
+from ..augment import mirror_augment
+
+
+# column axis of each field of a sampled batch (state, prob, value, winner, next_state, done); None = no board axis
+_MIRROR_AXIS = (3, 1, None, None, 3, None)
 
 
 def instant_augment(batch):
-    raise NotImplementedError("training-side augmentation is outside the self-play path (DESIGN.md section 7)")
+    """Doubles a sampled batch with its left-right mirror image (Connect4/utils.py:114-128): rows [0, B) are the
+    batch, rows [B, 2B) the mirrored twins (boards and pi reversed along the column axis, scalars repeated)."""
+    return mirror_augment(batch, _MIRROR_AXIS)
 
 
 def inspect(net, board=None):

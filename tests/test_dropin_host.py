@@ -87,6 +87,32 @@ def test_state_dict_to_blob_layout(dropin):
         CNN(0, h_dim=64)
 
 
+def test_instant_augment_mirrors_batch(dropin):
+    """Connect4/utils.py:114-128 and TTT/utils.py:74-89 restated in numpy: originals, then their column mirrors."""
+    import torch
+    rng = np.random.default_rng(5)
+    B = 6
+    c4 = (rng.random((B, 3, 6, 7), dtype=np.float32), rng.random((B, 7), dtype=np.float32),
+          rng.random((B, 1), dtype=np.float32), rng.integers(-1, 2, (B, 1)).astype(np.int32),
+          rng.random((B, 3, 6, 7), dtype=np.float32), rng.integers(0, 2, (B, 1)).astype(bool))
+    out = dropin.load("Connect4").instant_augment(tuple(torch.from_numpy(x) for x in c4))
+    axes = (3, 1, None, None, 3, None)
+    assert len(out) == 6
+    for o, x, ax in zip(out, c4, axes):
+        want = np.concatenate([x, x if ax is None else np.flip(x, ax)], 0)
+        assert o.dtype == torch.from_numpy(x).dtype and np.array_equal(o.numpy(), want)
+    # the mirror of a position's pi belongs to the mirrored position: column c <-> 6 - c
+    assert np.array_equal(out[1][B:, 0].numpy(), c4[1][:, 6]) and np.array_equal(out[0][B:, :, :, 0].numpy(), c4[0][:, :, :, 6])
+    ttt = (rng.random((B, 3, 3, 3), dtype=np.float32), rng.random((B, 9), dtype=np.float32),
+           rng.random((B, 1), dtype=np.float32), rng.random((B, 3, 3, 3), dtype=np.float32),
+           rng.integers(0, 2, (B, 1)).astype(bool), rng.integers(0, 2, (B, 9)).astype(bool))
+    out = dropin.load("TTT").instant_augment(tuple(torch.from_numpy(x) for x in ttt))
+    for o, x, ax in zip(out, ttt, (3, 1, None, 3, None, 1)):
+        assert np.array_equal(o.numpy(), np.concatenate([x, x if ax is None else np.flip(x, ax)], 0))
+    with pytest.raises(ValueError):
+        dropin.load("TTT").instant_augment(tuple(torch.from_numpy(x) for x in c4[:5]))
+
+
 def _bn(prefix, c):
     return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
             (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", None)]
