@@ -20,6 +20,10 @@ namespace az {
 
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
+static int bad_arg(const char* fn) {
+    set_error(std::string(fn) + ": bad argument (null pointer or count out of range)");
+    return AZ_ERR_ARG;
+}
 
 struct GameInfo {
     int A, W, LG, MAXD, MAX_PLIES;
@@ -553,6 +557,7 @@ int az_engine_sync(az_engine* e) {
     AZ_HIP(hipStreamSynchronize(e->stream));
     u32 err = 0;
     AZ_HIP(hipMemcpy(&err, e->d.err, sizeof(u32), hipMemcpyDeviceToHost));
+    if (err & 5u) AZ_HIP(hipMemset(e->d.err, 0, sizeof(u32)));  // reported once: the trees that fit stay readable
     if (err & 1u) {
         set_error("node arena overflow: raise az_config.nodes_per_game / max_plies");
         return AZ_ERR_ARENA;
@@ -566,7 +571,7 @@ int az_engine_sync(az_engine* e) {
 
 int az_get_config(az_engine* e, az_config* out) {
     AZ_CHECK_E(e);
-    if (!out) return AZ_ERR_ARG;
+    if (!out) return bad_arg("az_get_config");
     *out = e->cfg;
     out->nodes_per_game = e->d.cap;
     return AZ_OK;
@@ -574,7 +579,7 @@ int az_get_config(az_engine* e, az_config* out) {
 
 int az_get_stats(az_engine* e, az_stats* out) {
     AZ_CHECK_E(e);
-    if (!out) return AZ_ERR_ARG;
+    if (!out) return bad_arg("az_get_stats");
     AZ_HIP(hipStreamSynchronize(e->stream));
     unsigned long long st[ST_N];
     AZ_HIP(hipMemcpy(st, e->d.stats, sizeof(st), hipMemcpyDeviceToHost));
@@ -632,7 +637,7 @@ int az_get_profile(az_engine* e, double* ms /*[4]*/, int64_t* launches /*[4]*/) 
 
 int az_get_profile_busy(az_engine* e, double* busy_ms /*[4]*/) {
     AZ_CHECK_E(e);
-    if (!busy_ms) return AZ_ERR_ARG;
+    if (!busy_ms) return bad_arg("az_get_profile_busy");
     AZ_HIP(hipStreamSynchronize(e->stream));
     AZ_TRY(prof_harvest(e));
     for (int i = 0; i < 4; i++) busy_ms[i] = e->prof_busy[i];
@@ -654,7 +659,7 @@ int az_set_noise(az_engine* e, double alpha) {
 
 int az_set_n_playout(az_engine* e, int32_t n) {
     AZ_CHECK_E(e);
-    if (n <= 0) return AZ_ERR_ARG;
+    if (n <= 0) return bad_arg("az_set_n_playout");
     e->cfg.n_playout = n;
     e->d.S = n;
     return AZ_OK;
@@ -701,7 +706,7 @@ int az_reset_games(az_engine* e) {
 
 int az_set_roots(az_engine* e, const uint64_t* states) {
     AZ_CHECK_E(e);
-    if (!states) return AZ_ERR_ARG;
+    if (!states) return bad_arg("az_set_roots");
     const Dev& d = e->d;
     e->roll_started = false;
     e->roll_par = 0;
@@ -724,7 +729,7 @@ int az_get_roots(az_engine* e, uint64_t* states, int8_t* winner, uint8_t* done) 
 
 int az_set_flip_stream(az_engine* e, const uint8_t* bits, int64_t n_per_game) {
     AZ_CHECK_E(e);
-    if (!bits || n_per_game <= 0) return AZ_ERR_ARG;
+    if (!bits || n_per_game <= 0) return bad_arg("az_set_flip_stream");
     AZ_HIP(hipStreamSynchronize(e->stream));
     if (e->flip_bits) (void)hipFree(e->flip_bits);
     e->flip_bits = nullptr;
@@ -837,7 +842,7 @@ int az_select(az_engine* e, uint64_t* leaf_states, uint8_t* flags) {
 
 int az_backup(az_engine* e, const float* probs, const float* values) {
     AZ_CHECK_E(e);
-    if (!probs || !values) return AZ_ERR_ARG;
+    if (!probs || !values) return bad_arg("az_backup");
     const Dev& d = e->d;
     AZ_HIP(hipMemcpyAsync(d.eval_probs, probs, (size_t)d.G * d.A * sizeof(float), hipMemcpyHostToDevice, e->stream));
     AZ_HIP(hipMemcpyAsync(d.eval_value, values, (size_t)d.G * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -878,8 +883,14 @@ int az_choose_moves(az_engine* e, const double* temps, double temp_all, int32_t*
 
 int az_advance(az_engine* e, const int32_t* actions) {
     AZ_CHECK_E(e);
-    if (!actions) return AZ_ERR_ARG;
+    if (!actions) return bad_arg("az_advance");
     const Dev& d = e->d;
+    for (int g = 0; g < d.G; g++)  // < 0 = leave the game where it is; the kernels index boards with the rest
+        if (actions[g] >= d.A) {
+            set_error("az_advance: action " + std::to_string(actions[g]) + " of game " + std::to_string(g) +
+                      " is outside [0, " + std::to_string(d.A) + ")");
+            return AZ_ERR_ARG;
+        }
     AZ_HIP(hipMemcpyAsync(e->d_actions, actions, d.G * 4, hipMemcpyHostToDevice, e->stream));
     AZ_TRY(launch_advance(d, e->p, e->d_actions, e->d_pi, e->cfg.reuse_tree, 0, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
@@ -968,7 +979,7 @@ int az_selfplay_rounds(az_engine* e, int32_t n_rounds, double temp, int32_t firs
 
 int64_t az_selfplay_rolling(az_engine* e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_calls) {
     AZ_CHECK_E(e);
-    if (n_games_target <= 0) return AZ_ERR_ARG;
+    if (n_games_target <= 0) return bad_arg("az_selfplay_rolling");
     AZ_TRY(az_reset_games(e));
     unsigned long long zero = 0;
     AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
@@ -1000,7 +1011,7 @@ int az_set_game_target(az_engine* e, int64_t n_games_target) {
 
 int64_t az_selfplay(az_engine* e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_steps) {
     AZ_CHECK_E(e);
-    if (n_games_target <= 0) return AZ_ERR_ARG;
+    if (n_games_target <= 0) return bad_arg("az_selfplay");
     AZ_TRY(az_reset_games(e));
     unsigned long long zero = 0;
     AZ_HIP(hipMemcpy(e->p.out_count, &zero, 8, hipMemcpyHostToDevice));
@@ -1071,7 +1082,7 @@ int64_t az_traj_pack_dev(az_engine* e, int64_t max_plies, void* out_dev, int cle
     AZ_TRY(az_traj_count(e, &ng, &np));
     int64_t n = np < max_plies ? np : max_plies;
     if (n > 0) {
-        if (!out_dev) return AZ_ERR_ARG;
+        if (!out_dev) return bad_arg("az_traj_pack_dev");
         AZ_TRY(launch_traj_pack(e->cfg.game, e->p, n, (u8*)out_dev, e->stream));
         AZ_HIP(hipStreamSynchronize(e->stream));
     }
@@ -1117,7 +1128,7 @@ int az_net_forward(az_engine* e, int64_t n, const uint64_t* states, float* logp,
         set_error("az_net_forward: call az_net_load first");
         return AZ_ERR_NO_NET;
     }
-    if (n < 0 || !states) return AZ_ERR_ARG;
+    if (n < 0 || !states) return bad_arg("az_net_forward");
     if (n == 0) return AZ_OK;
     TmpBufs t;
     u64* ds;

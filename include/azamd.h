@@ -125,7 +125,10 @@ int az_env_step_batch_dev(int game, int64_t n, const uint64_t *states_in_dev, co
 /* ---- engine life cycle ------------------------------------------------------------------------------ */
 int az_engine_create(const az_config *cfg, az_engine **out);
 void az_engine_destroy(az_engine *e);
-int az_engine_sync(az_engine *e);                    /* hipStreamSynchronize on the engine stream         */
+/* hipStreamSynchronize on the engine stream.  Also where the kernels' overflow flags surface: AZ_ERR_ARENA when an
+ * expansion did not fit the node arena (that leaf stayed a leaf) or a finished game did not fit the trajectory
+ * buffer (that game was dropped).  The flag is reported once and cleared; nothing is written out of bounds. */
+int az_engine_sync(az_engine *e);
 /* the configuration in force, with every 0 = auto field resolved (c_base, nodes_per_game, n_cohorts). */
 int az_get_config(az_engine *e, az_config *out);
 int az_get_stats(az_engine *e, az_stats *out);
@@ -172,7 +175,8 @@ int az_get_root_children(az_engine *e, int32_t *actions, int32_t *visits, float 
 /* AlphaZeroPlayer.get_action after the search (player.py:104-111): pi[G][A] = softmax(ln N / max(T,1e-8)) as
  * float32, and the move (first-max or sampled, per cfg.move_mode).  temps[G] (or NULL -> temp_all). */
 int az_choose_moves(az_engine *e, const double *temps, double temp_all, int32_t *actions, float *pi);
-/* play actions[G] (<0: leave the slot alone): env.step + prune_root(action) / fresh root (player.py:112-115). */
+/* play actions[G] (<0: leave the slot alone): env.step + prune_root(action) / fresh root (player.py:112-115).
+ * An action >= az_n_actions(game) is AZ_ERR_ARG and nothing is played. */
 int az_advance(az_engine *e, const int32_t *actions);
 
 /* ---- self-play collector (game.py:35-58 for G games at once, Pipeline.py:53-63) ------------------------ */
