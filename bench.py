@@ -99,6 +99,20 @@ def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=8.0):
     return out
 
 
+def _box_info(torch, local):
+    """what the numbers were measured on (GPU, clocks, host cores), read outside the timed region"""
+    info = {"host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        info.update(gpu=pr.name, arch=getattr(pr, "gcnArchName", ""), cus=pr.multi_processor_count,
+                    hbm_gib=round(pr.total_memory / 2**30, 1))
+        if getattr(pr, "clock_rate", 0):
+            info["max_sclk_mhz"] = pr.clock_rate / 1e3
+    except Exception as ex:  # never let a property lookup cost the bench line
+        info["gpu"] = "unknown (%s)" % type(ex).__name__
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +243,7 @@ def main():
                          "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
                          "executed_frac": achieved * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS},
             "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
+            "box": _box_info(torch, local),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, S, mean_len, args.cpu_budget)
