@@ -99,6 +99,20 @@ def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=8.0):
     return out
 
 
+def cpu_baseline_pure(n_playout=1000, searches=6):
+    """cpu_baseline leg of the pure-MCTS measurement (tools/bench_configs.py pure): the C port of the
+    reference's UCT + random-rollout search, root searches of the empty Connect4 board on one host core."""
+    from oracle import oracle as orc
+    t = orc.PureMCTS("Connect4", 1.0, n_playout, seed=1)
+    c0 = time.perf_counter()
+    for _ in range(searches):
+        t.reset()
+        t.get_action(orc.Env("Connect4"))
+    cdt = time.perf_counter() - c0
+    return {"playouts_per_s": searches * n_playout / cdt, "cores": 1, "kind": "port",
+            "sample": "%d root searches x %d playouts, oracle/az_oracle_pure.c" % (searches, n_playout)}
+
+
 def _box_info(torch, local):
     """what the numbers were measured on (GPU, clocks, host cores), read outside the timed region"""
     info = {"host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}

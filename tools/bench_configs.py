@@ -121,7 +121,7 @@ def bench_tree(game, G, S, c_puct, evaluator, plies, first_n, label):
 
 def bench_pure(args):
     """the Elo arena's opponent, pure MCTS (UCT + random rollouts), MCTSPlayer(1, 1000) of
-    Pipeline.py:130 for 4096 Connect4 games at once; beside it the CPU oracle (C port, 1 core) on one game's moves."""
+    Pipeline.py:130 for 4096 Connect4 games at once; beside it bench.py's cpu_baseline leg for this search (C port, 1 core)."""
     from alphazero_amd.engine import SelfPlayEngine
     G, S = 4096, 1000
     eng = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.0, evaluator="rollout", flip="random",
@@ -137,21 +137,14 @@ def bench_pure(args):
     eng.sync()
     dt = time.perf_counter() - t0
     st, prof = eng.stats(), eng.get_profile()
-    from oracle import oracle as orc
-    t = orc.PureMCTS("Connect4", 1.0, S, seed=1)
-    c0 = time.perf_counter()
-    for _ in range(6):
-        t.reset()
-        t.get_action(orc.Env("Connect4"))
-    cdt = time.perf_counter() - c0
+    from bench import cpu_baseline_pure   # the CPU port is timed by bench.py's cpu_baseline leg, nowhere else
     print(json.dumps({"bench": "pure_mcts_c4_4096x1000", "kernel": "k_search_pure<C4>", "games": G,
                       "playouts_per_move": S, "wall_s": dt, "playouts_per_s": st["playouts"] / dt,
                       "rollout_plies_per_s": st["rollout_plies"] / dt,
                       "mean_rollout_plies": st["rollout_plies"] / max(st["leaf_evals"], 1),
                       "mean_depth": st["levels"] / max(st["playouts"], 1),
                       "avg_launch_ms": prof["fused"]["ms"] / max(prof["fused"]["launches"], 1),
-                      "cpu_baseline": {"playouts_per_s": 6 * S / cdt, "cores": 1, "kind": "port",
-                                       "sample": "6 root searches x %d playouts, oracle/az_oracle_pure.c" % S}}), flush=True)
+                      "cpu_baseline": cpu_baseline_pure(S)}), flush=True)
     eng.close()
 
 
