@@ -53,7 +53,7 @@ class Game:
 
     def collect_self_play(self, player, buffer, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
         """Pipeline.data_collector (Pipeline.py:53-63) in one call: play n_games in lockstep on the device with player's
-        search settings and write every ply into `buffer` (a reference ReplayBuffer whose tensors live on the GPU)
+        search settings and write every ply into `buffer` (the drop-in ReplayBuffer, or the reference's, with its tensors on the GPU)
         with collector.store_many -- trajectories never visit the host.  Under torch.distributed every rank plays
         n_games and every rank's buffer receives the plies of ALL ranks (RCCL all-gather of packed records).
         Returns the list of episode lengths of the games stored (data_collector's episode_len is their mean)."""
@@ -76,7 +76,10 @@ class Game:
             recs = TrajectoryGatherer(eng, torch.device("cuda", dev_index)).gather()
         finally:
             eng.close()
-        store_many(buffer, recs, game)
+        if hasattr(buffer, "store_many"):    # the drop-in ReplayBuffer keeps its row counter itself
+            buffer.store_many(recs, game)
+        else:                                # the reference's own ReplayBuffer object
+            store_many(buffer, recs, game)
         done_col = eng.W * 8 + eng.A * 4 + 3
         ends = torch.nonzero(recs[:, done_col]).flatten().cpu().numpy()
         return [int(x) for x in np.diff(np.concatenate([[-1], ends]))]

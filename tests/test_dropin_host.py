@@ -113,6 +113,58 @@ def test_instant_augment_mirrors_batch(dropin):
         dropin.load("TTT").instant_augment(tuple(torch.from_numpy(x) for x in c4[:5]))
 
 
+def test_replaybuffer_hands_out_the_reference_rows(dropin):
+    """dropin/ReplayBuffer.py vs rows recorded from the reference's ReplayBuffer (tests/golden/replay.npz, made by
+    make_fixtures_replay.py): same plies stored, same torch / numpy seeds -> the same rows in the same order from
+    dataloader (ReplayBuffer.py:94-151), sample_balanced (:153-185) and sample (:89-92); len, ring pointer, is_full."""
+    import json
+    import torch
+    from ReplayBuffer import ReplayBuffer
+    sys.path.insert(0, G)
+    try:
+        from make_fixtures_replay import store_all, synthetic_plies
+    finally:
+        sys.path.remove(G)
+    fx = np.load(os.path.join(G, "replay.npz"))
+    meta = json.loads(bytes(fx["meta"]).decode())
+    assert len(meta["cases"]) >= 7
+    for i, m in enumerate(meta["cases"]):
+        done, winner = synthetic_plies(m["n"], m["p_done"], m["outcomes"], 1000 + m["seed"])
+        buf = ReplayBuffer(1, m["capacity"], 2, 1, 2, replay_ratio=m["replay_ratio"], device="cpu",
+                           balance_done_value=m["balance"])
+        assert len(buf) == 0 and not buf.is_full()
+        store_all(buf, m["n"], done, winner)
+        assert (len(buf), buf._ptr, buf.is_full()) == (m["len"], m["ptr"], m["is_full"]), i
+        assert buf.recount() == m["len"]                       # the counter agrees with the reference's NaN scan
+        torch.manual_seed(m["seed"])
+        dl = buf.dataloader(32)
+        got = dl.dataset.tensors[2].reshape(-1).numpy().astype(np.int64)
+        assert np.array_equal(got, fx["case%d_dataloader" % i]), i
+        batch = next(iter(dl))
+        assert len(batch) == 6 and batch[0].shape[1:] == (1, 1, 2) and batch[5].dtype == torch.bool
+        torch.manual_seed(m["seed"] + 100)
+        dl = buf.sample_balanced(32)
+        assert np.array_equal(dl.dataset.tensors[2].reshape(-1).numpy().astype(np.int64), fx["case%d_balanced" % i]), i
+        assert dl.batch_size == m["balanced_batch"]
+        np.random.seed(m["seed"])
+        assert np.array_equal(buf.sample(50)[2].reshape(-1).numpy().astype(np.int64), fx["case%d_sample" % i]), i
+    # rows keep what store() was given (value k at the row the ring pointer named), reset() empties the buffer
+    k = int(buf.value[7, 0])
+    assert buf.state[7, 0, 0, 0] == k and buf.next_state[7, 0, 0, 1] == k + 0.5 and buf.prob[7, 1] == -k
+    buf.reset()
+    assert len(buf) == 0 and buf._ptr == 0 and bool(buf.value.isnan().all())
+    with pytest.raises(ValueError):
+        buf.dataloader(8)
+    # double(): the ring window grows up to the allocated rows and the pointer moves behind the data
+    buf.current_capacity = 500
+    store_all(buf, 500, done, winner)
+    assert (len(buf), buf._ptr) == (500, 0)
+    buf.double()
+    assert (buf.current_capacity, buf._ptr) == (1000, 500)
+    with pytest.raises(Exception):
+        buf.store_many(torch.zeros((4, 48), dtype=torch.uint8))   # CPU tensors: the unpack kernel has no CPU path
+
+
 def _bn(prefix, c):
     return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
             (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", None)]

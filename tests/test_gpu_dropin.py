@@ -339,3 +339,70 @@ def test_collect_self_play_into_reference_shaped_buffer(dropin):
         zz = z[lo:lo + ln]
         assert (zz[::-1][0::2] == zz[-1]).all() and (zz[::-1][1::2] == -zz[-1]).all()
         lo += ln
+
+
+def test_dropin_replaybuffer_collects_and_serves_batches_on_device(dropin):
+    """SURVEY 8f-1 end to end with the drop-in's own ReplayBuffer on the GPU: collect_self_play -> store_many (unpack
+    kernel, ring wrap at current_capacity) -> len without a NaN scan -> dataloader / sample_balanced / sample hand out
+    device-resident rows that are whole plies; the same rows land where per-ply store() puts them."""
+    import torch
+    from ReplayBuffer import ReplayBuffer
+    from alphazero_amd.collector import TrajectoryGatherer
+    from alphazero_amd.engine import SelfPlayEngine
+    module = dropin["load"]("Connect4")
+    net = module.CNN(0, device="cuda")
+    net.load(os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32"))
+    sp = dropin["player"].AlphaZeroPlayer(net, c_puct=1.25, n_playout=24, alpha=0.7, is_selfplay=1)
+    sp.train()
+    buf = ReplayBuffer(3, 4096, 7, 6, 7, replay_ratio=0.25, device="cuda")
+    lens = dropin["game"].Game(module.Env()).collect_self_play(sp, buf, 64, temp=1.0, first_n_steps=10)
+    n = sum(lens)
+    assert len(buf) == n == buf._ptr and buf.recount() == n and not buf.is_full()
+    torch.manual_seed(0)
+    dl = buf.dataloader(128)
+    rows = dl.dataset.tensors
+    budget = n if n <= 1000 else min(int(n * 0.25), 10000)
+    quota = max(1, int(budget * 0.2))                                # game-ending plies asked for (ReplayBuffer.py:108)
+    n_end = int(rows[5].sum().item())
+    end_w = buf.winner[:n][buf.done[:n]].reshape(-1)
+    classes = torch.unique(end_w)
+    want_end = sum(min(int((end_w == v).sum()), quota // len(classes) + (1 if i < quota % len(classes) else 0))
+                   for i, v in enumerate(classes))
+    assert all(t.is_cuda for t in rows) and n_end == want_end and rows[0].shape[0] == n_end + budget - quota
+    assert len(torch.unique(rows[0].reshape(rows[0].shape[0], -1), dim=0)) >= 0.5 * rows[0].shape[0]
+    state, prob, value, winner, nxt, done = next(iter(dl))
+    assert state.shape[1:] == (3, 6, 7) and prob.shape[1:] == (7,) and done.dtype == torch.bool
+    assert not torch.isnan(state).any() and torch.equal(value.to(torch.int32), winner)
+    placed = (nxt[:, 0] + nxt[:, 1]).sum((1, 2)) - (state[:, 0] + state[:, 1]).sum((1, 2))
+    assert (placed == 1).all()                                     # next_state = state + the move that was played
+    assert torch.equal(nxt[:, 2], -state[:, 2])                    # and the turn plane changes sign
+    s6 = buf.sample(33)
+    assert s6[0].shape == (33, 3, 6, 7) and s6[0].is_cuda
+    bl = buf.sample_balanced(64)
+    w, allw = bl.dataset.tensors[3].reshape(-1), buf.winner[:n].reshape(-1)
+    total = min(n, 1024)                                             # min(len, replay_ratio * allocated rows, 10000)
+    classes = torch.unique(allw)
+    for i, v in enumerate(classes):                                  # outcomes evenly represented, as far as they exist
+        q = total // len(classes) + (1 if i < total % len(classes) else 0)
+        assert int((w == v).sum()) == min(q, int((allw == v).sum()))
+    # store_many == a loop of store(): same rows, same pointer, ring wrap included
+    eng = SelfPlayEngine("Connect4", n_games=16, n_playout=20, evaluator="hash", eval_seed=9, move="first_max")
+    eng.selfplay(16, temp=1.0, first_n_steps=4)
+    tr = eng.traj_fetch(clear=False)
+    recs = TrajectoryGatherer(eng, torch.device("cuda", 0)).gather()
+    m = len(tr["z"])
+    a = ReplayBuffer(3, m + 50, 7, 6, 7, device="cuda")
+    b = ReplayBuffer(3, m + 50, 7, 6, 7, device="cuda")
+    a.current_capacity = b.current_capacity = m - 9
+    a._ptr = b._ptr = 4
+    assert a.store_many(recs, "Connect4") == 4
+    for i in range(m):
+        env = orc.Env.from_packed("Connect4", tr["states"][i])
+        s = env.current_state()
+        env.step(int(tr["action"][i]))
+        b.store(s, tr["pi"][i], float(tr["z"][i]), float(tr["z"][i]), env.current_state(), bool(tr["done"][i]))
+    assert (len(a), a._ptr) == (len(b), b._ptr) == (m - 9, (4 + m) % (m - 9))
+    for name in ("state", "prob", "value", "winner", "next_state", "done"):
+        x, y = getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()
+        assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), name
+    eng.close()
