@@ -171,3 +171,41 @@ def test_store_many_equals_per_ply_store(E):
         a, b = getattr(bulk, name).cpu().numpy(), getattr(ply, name).cpu().numpy()
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), name
     eng.close()
+
+
+def test_unpack_rows_do_not_depend_on_where_the_ring_pointer_stands(E):
+    """az_traj_unpack_dev peels the plies before the first 128-byte line boundary and the ragged tail off to a
+    narrower kernel and streams the middle in 32-ply chunks: whatever row the destination starts at (every residue
+    mod 16 moves the boundary) and whatever the count, the rows written are the rows of the pinned case above and
+    nothing outside [lo, lo + n) is touched."""
+    import torch
+    from alphazero_amd.collector import TrajectoryGatherer, store_many
+    eng = E.SelfPlayEngine("Connect4", n_games=48, n_playout=16, evaluator="hash", eval_seed=11, flip="never",
+                           move="first_max")
+    eng.selfplay(48, temp=1.0, first_n_steps=8)
+    dev = torch.device("cuda", 0)
+    recs = TrajectoryGatherer(eng, dev).gather()
+    eng.close()
+    n = int(recs.shape[0])
+    assert n > 400
+    ref = _RefShapedBuffer(3, n, 7, 6, 7, dev)
+    store_many(ref, recs, "Connect4")
+    names = ("state", "prob", "value", "winner", "next_state", "done")
+    for lo, m in [(0, n), (1, n), (3, n - 1), (7, 100), (8, 31), (15, 33), (16, 64), (17, 65), (29, n - 5), (2, 1),
+                  (2, 0)]:
+        buf = _RefShapedBuffer(3, n + 64, 7, 6, 7, dev)
+        buf.winner.fill_(-7)
+        buf.done.fill_(True)
+        buf._ptr = lo
+        store_many(buf, recs[:m], "Connect4")
+        assert buf._ptr == lo + m
+        for name in names:
+            got, want = getattr(buf, name), getattr(ref, name)
+            assert torch.equal(got[lo:lo + m], want[:m]), (lo, m, name)     # written rows hold no NaN
+            rest = torch.cat([got[:lo], got[lo + m:]])
+            if got.dtype == torch.float32:
+                assert torch.isnan(rest).all(), (lo, m, name)
+            elif got.dtype == torch.int32:
+                assert (rest == -7).all(), (lo, m, name)
+            else:
+                assert rest.all(), (lo, m, name)

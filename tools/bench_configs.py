@@ -179,9 +179,73 @@ def bench_c4big(args):
     eng.close()
 
 
+def bench_unpack(args):
+    """packed ply records -> ReplayBuffer rows (k_traj_unpack<C4>), the bulk form of buffer.store.
+    Algorithmic bytes per ply: 48 in + 2 x 504 (state, next_state) + 28 (pi) + 4 + 4 + 1 = 1 093 B, all but 48 written."""
+    import torch
+    from alphazero_amd import _abi
+    L = _abi.lib()
+    _abi.require_gpu()
+    n = args.unpack_n
+    rng = np.random.default_rng(1)
+    vp = C.c_void_p
+    st = torch.zeros((n, 2), dtype=torch.int64, device="cuda")      # positions 12 random plies into a game (K1)
+    out = torch.empty_like(st)
+    for _ in range(12):
+        a = torch.from_numpy(rng.integers(0, 7, size=n).astype(np.int32)).cuda()
+        _abi.check(L.az_env_step_batch_dev(0, n, vp(st.data_ptr()), vp(a.data_ptr()), vp(out.data_ptr()), None, None,
+                                           None, None))
+        st.copy_(out)
+    recs = torch.empty((n, 48), dtype=torch.uint8, device="cuda")
+    recs[:, :16] = st.view(torch.uint8).reshape(n, 16)
+    recs[:, 16:44] = torch.rand((n, 7), device="cuda").view(torch.uint8).reshape(n, 28)
+    recs[:, 44:48] = torch.from_numpy(np.stack([rng.integers(-1, 2, n), rng.choice([-1, 1], n), rng.integers(0, 7, n),
+                                                rng.integers(0, 2, n)], 1).astype(np.int8)).cuda().view(torch.uint8)
+    state = torch.empty((n, 3, 6, 7), dtype=torch.float32, device="cuda")
+    nxt = torch.empty_like(state)
+    prob = torch.empty((n, 7), dtype=torch.float32, device="cuda")
+    value = torch.empty((n, 1), dtype=torch.float32, device="cuda")
+    winner = torch.empty((n, 1), dtype=torch.int32, device="cuda")
+    done = torch.empty((n, 1), dtype=torch.uint8, device="cuda")
+
+    def run():
+        _abi.check(L.az_traj_unpack_dev(0, n, vp(recs.data_ptr()), vp(state.data_ptr()), vp(prob.data_ptr()),
+                                        vp(value.data_ptr()), vp(winner.data_ptr()), vp(nxt.data_ptr()),
+                                        vp(done.data_ptr())))
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()          # az_traj_unpack_dev launches on stream 0 = torch's current (default) stream
+    for _ in range(args.reps):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / args.reps
+    bytes_per = 48 + 2 * 504 + 28 + 4 + 4 + 1
+    gbs = n * bytes_per / (ms * 1e-3) / 1e9
+    # spot check against the planes kernel (env.current_state) so that a fast wrong kernel cannot pass for a result
+    from alphazero_amd.engine import env_planes_batch
+    ref = env_planes_batch("Connect4", st[:1024].cpu().numpy().view(np.uint64))
+    assert np.array_equal(ref, state[:1024].cpu().numpy())
+    # what a plain device fill of the two plane tensors reaches on this box (write-only stream of the same size)
+    ev0.record()
+    for _ in range(args.reps):
+        state.fill_(1.0)
+        nxt.fill_(1.0)
+    ev1.record()
+    torch.cuda.synchronize()
+    fill_gbs = 2 * n * 504 / (ev0.elapsed_time(ev1) / args.reps * 1e-3) / 1e9
+    print(json.dumps({"bench": "traj_unpack_c4", "kernel": "k_traj_unpack<C4>", "plies": n, "avg_launch_ms": ms,
+                      "plies_per_s": n / (ms * 1e-3), "bytes_per_ply": bytes_per, "torch_fill_same_tensors_gbs": fill_gbs,
+                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": gbs / 8000.0}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", nargs="+", choices=["k1", "ttt", "nbttt", "c4big", "pure"])
+    ap.add_argument("which", nargs="+", choices=["k1", "ttt", "nbttt", "c4big", "pure", "unpack"])
+    ap.add_argument("--unpack-n", type=int, default=1 << 21)
     ap.add_argument("--n", type=int, default=1 << 24)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--games", type=int, default=16384)
@@ -199,6 +263,8 @@ def main():
             bench_c4big(args)
         elif w == "pure":
             bench_pure(args)
+        elif w == "unpack":
+            bench_unpack(args)
 
 
 if __name__ == "__main__":
