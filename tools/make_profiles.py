@@ -77,7 +77,7 @@ def main():
         f.write("# derived: HBM traffic per launch = 2 x %.0f KB + %.0f KB = %.1f MB\n" % (kf[0], kw[0], (2 * kf[0] + kw[0]) / 1024))
     # 3. tree + env
     with open(os.path.join(P, R + "_tree_env_pmc.txt"), "w") as f:
-        f.write("# tree + env kernels: rocprofv3 -- python3 tools/bench_configs.py k1 ttt nbttt pure   (kernel-trace pass, FETCH_SIZE "
+        f.write("# tree + env kernels: rocprofv3 -- python3 tools/bench_configs.py k1 ttt nbttt pure unpack   (kernel-trace pass, FETCH_SIZE "
                 "pass, WRITE_SIZE pass; KB per dispatch)\n")
         f.write(cap(rs.kernel_stats, os.path.join(O, "tree", "tree_results.db")))
         for p in ("tree_fetch", "tree_write"):
