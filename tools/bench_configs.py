@@ -236,7 +236,7 @@ def bench_unpack(args):
     ev1.record()
     torch.cuda.synchronize()
     fill_gbs = 2 * n * 504 / (ev0.elapsed_time(ev1) / args.reps * 1e-3) / 1e9
-    print(json.dumps({"bench": "traj_unpack_c4", "kernel": "k_traj_unpack<C4>", "plies": n, "avg_launch_ms": ms,
+    print(json.dumps({"bench": "traj_unpack_c4", "kernel": "k_traj_unpack_c4_lines", "plies": n, "avg_launch_ms": ms,
                       "plies_per_s": n / (ms * 1e-3), "bytes_per_ply": bytes_per, "torch_fill_same_tensors_gbs": fill_gbs,
                       "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
                                    "frac": gbs / 8000.0}}), flush=True)
