@@ -17,11 +17,12 @@ from . import _abi
 PLANES = {0: (3, 6, 7), 1: (3, 3, 3), 2: (28, 3, 3)}
 
 
-def gather_records(local, group=None):
+def gather_records(local, group=None, force=False):
     """All-gather a ragged [n_i, rec] uint8 tensor across ranks (counts first, then a padded all_gather).
-    Pure torch.distributed: works with nccl (device tensors) and gloo (CPU tensors, used by the CPU tests)."""
+    Pure torch.distributed: works with nccl (device tensors) and gloo (CPU tensors, used by the CPU tests).
+    `force` runs the collectives in a group of one as well (tools/rccl_selftest.py)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     rec = local.shape[1]
