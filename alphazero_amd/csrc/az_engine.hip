@@ -604,7 +604,7 @@ int az_set_profiling(az_engine* e, int on) {
     AZ_HIP(hipStreamSynchronize(e->stream));
     AZ_TRY(prof_harvest(e));
     if (on && e->prof_ev.empty()) {
-        const size_t pairs = 65536;   // a whole bench window of K3 launches: the read-back happens after the timed region
+        const size_t pairs = 131072;   // a whole bench window of K3 launches: the read-back happens after the timed region
         e->prof_ev.resize(2 * pairs);
         e->prof_cat.resize(pairs);
         for (auto& ev : e->prof_ev) AZ_HIP(hipEventCreate(&ev));

@@ -137,8 +137,8 @@ def _box_info(torch, local):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--games", type=int, default=2048, help="concurrent game slots per GPU")
     ap.add_argument("--playouts", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
