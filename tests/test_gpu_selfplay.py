@@ -55,26 +55,28 @@ def test_selfplay_trajectories_vs_oracle(E, game, S, c, first_n):
     eng.close()
 
 
-def test_pack_gather_unpack_replay_tensors(E):
-    """finished plies -> packed 48-byte records -> (world size 1 gather) -> ReplayBuffer-shaped device tensors;
-    compared with the tuples game.py:58 would have produced (state, pi, z, z, next_state, done)."""
+@pytest.mark.parametrize("game,rec_bytes,Gn", [("Connect4", 48, 16), ("TTT", 48, 40), ("NBTTT", 72, 12)])
+def test_pack_gather_unpack_replay_tensors(E, game, rec_bytes, Gn):
+    """finished plies -> packed records -> (world size 1 gather) -> ReplayBuffer-shaped device tensors; compared with
+    the tuples game.py:58 would have produced (state, pi, z, z, next_state, done), for every game's plane format
+    (env_cython.pyx:143-149, TTT/utils.py:5-11, NBTTT/utils.py:258-268)."""
     import torch
     from alphazero_amd.collector import ReplaySink, TrajectoryGatherer
-    Gn, S = 16, 30
-    eng = E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, evaluator="hash", eval_seed=1, flip="never",
+    S = 30
+    eng = E.SelfPlayEngine(game, n_games=Gn, n_playout=S, evaluator="hash", eval_seed=1, flip="never",
                            move="first_max")
     eng.selfplay(Gn, temp=1.0, first_n_steps=4)
     tr = eng.traj_fetch(clear=False)
     dev = torch.device("cuda", 0)
     recs = TrajectoryGatherer(eng, dev).gather()
-    assert recs.shape == (len(tr["z"]), 48) and eng.traj_count() == (0, 0)
-    sink = ReplaySink("Connect4", capacity=len(tr["z"]) + 7, device=dev)
+    assert recs.shape == (len(tr["z"]), rec_bytes) and eng.traj_count() == (0, 0)
+    sink = ReplaySink(game, capacity=len(tr["z"]) + 7, device=dev)
     sink.store_packed(recs)
     n = len(tr["z"])
     assert len(sink) == n and sink.games_seen == Gn and sink.plies_seen == n
     st, ns = sink.state[:n].cpu().numpy(), sink.next_state[:n].cpu().numpy()
     for i in range(n):
-        env = orc.Env.from_packed("Connect4", tr["states"][i])
+        env = orc.Env.from_packed(game, tr["states"][i])
         assert np.array_equal(st[i], env.current_state()[0])
         env.step(int(tr["action"][i]))
         assert np.array_equal(ns[i], env.current_state()[0])
