@@ -258,6 +258,113 @@ __global__ __launch_bounds__(256) void k_traj_unpack_c4_lines(i64 n_chunks, cons
     }
 }
 
+// The same whole-line scheme for the other two plane formats (TTT: 27 floats per ply, 32 plies = 27 lines; NBTTT: 252
+// floats, 8 plies = 63 lines).  Every plane element is one 64-bit word of the position plus a rule: a bit of it
+// (stones), its top bit (turn plane), or its low nibble compared with a constant (NBTTT "current board" planes); the
+// words of the chunk's positions before and after the move sit in LDS and each lane reads the word each of its
+// elements needs (which ply, which word, which rule: worked out once, before the loop).
+template <class G>
+struct UnpackGeo {
+    static constexpr int PL = G::GAME == AZ_GAME_TTT ? 27 : 252;  // floats per ply
+    static constexpr int CH = G::GAME == AZ_GAME_TTT ? 32 : 8;    // plies per chunk: CH * PL * 4 bytes = whole lines
+    static constexpr int NF4 = CH * PL / 4;
+    static constexpr int K = (NF4 + 255) / 256;
+};
+template <class G>
+__device__ inline u32 plane_rule(int r) {  // bits 0-5 bit, 6-7 word, 8-9 kind (0 bit, 1 turn, 2 nibble == k), 10-13 k
+    const int ch = r / 9, q = r % 9;
+    if constexpr (G::GAME == AZ_GAME_TTT) {  // TTT/utils.py:5-11
+        if (ch == 0) return (u32)q;
+        if (ch == 1) return (u32)(16 + q);
+        return 1u << 8;
+    } else {  // NBTTT/utils.py:258-268 with 0-based current-board planes
+        if (ch < 9) return (u32)(18 * (ch % 3) + q) | ((u32)(ch / 3) << 6);
+        if (ch < 18) return (u32)(18 * ((ch - 9) % 3) + 9 + q) | ((u32)((ch - 9) / 3) << 6);
+        if (ch < 27) return (2u << 8) | (3u << 6) | ((u32)(ch - 18) << 10);
+        return (1u << 8) | (3u << 6);
+    }
+}
+__device__ inline float plane_by_rule(u64 w, u32 rule) {
+    const u32 kind = (rule >> 8) & 3u;
+    const float bit = (float)(u32)((w >> (rule & 63u)) & 1ull);
+    const float turn = (w >> 63) ? -1.f : 1.f;
+    const float is_k = ((u32)(w & 15ull) == ((rule >> 10) & 15u)) ? 1.f : 0.f;
+    return kind == 0 ? bit : (kind == 1 ? turn : is_k);
+}
+template <class G>
+__global__ __launch_bounds__(256) void k_traj_unpack_lines(i64 n_chunks, const u8* __restrict__ recs,
+                                                           float* __restrict__ state, float* __restrict__ prob,
+                                                           float* __restrict__ value, i32* __restrict__ winner,
+                                                           float* __restrict__ next_state, u8* __restrict__ done) {
+    using Geo = UnpackGeo<G>;
+    constexpr int REC = G::W * 8 + G::A * 4 + 4, PL = Geo::PL, CH = Geo::CH, W = G::W;
+    __shared__ u64 cur[CH * W], nxt[CH * W];
+    const int tid = threadIdx.x;
+    u32 slot[Geo::K][4];  // per element: LDS word index (bits 16+) | rule
+#pragma unroll
+    for (int k = 0; k < Geo::K; k++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = 4 * (tid + 256 * k) + j;
+            const int pl = e < CH * PL ? e / PL : 0, r = e < CH * PL ? e - PL * pl : 0;
+            const u32 rule = plane_rule<G>(r);
+            slot[k][j] = rule | ((u32)(pl * W + (int)((rule >> 6) & 3u)) << 16);
+        }
+    }
+    for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const i64 base = c * CH;
+        if (tid < CH) {
+            const i64 i = base + tid;
+            const u8* rec = recs + i * REC;
+            typename G::State s;
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                s.w[k] = reinterpret_cast<const u64*>(rec)[k];
+                cur[tid * W + k] = s.w[k];
+            }
+            const u32 meta = *reinterpret_cast<const u32*>(rec + W * 8 + G::A * 4);  // i8 z | player | action | u8 done
+            const int z = (int)(i8)(meta & 0xFFu);
+            G::step(s, (int)(i8)((meta >> 16) & 0xFFu));  // game.py:48-49
+#pragma unroll
+            for (int k = 0; k < W; k++) nxt[tid * W + k] = s.w[k];
+            if (value) value[i] = (float)z;
+            if (winner) winner[i] = (i32)z;
+            if (done) done[i] = (u8)(meta >> 24);
+        }
+        if (prob) {
+            for (int t = tid; t < CH * G::A; t += 256) {
+                const int pl = t / G::A, a = t - G::A * pl;
+                prob[base * G::A + t] = reinterpret_cast<const float*>(recs + (base + pl) * REC + W * 8)[a];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < Geo::K; k++) {
+            const int f = tid + 256 * k;
+            if (f < Geo::NF4) {
+                const i64 o = base * PL / 4 + f;  // base is a multiple of CH plies and CH * PL of 4
+                if (state) {
+                    f32x4 v;
+                    v.x = plane_by_rule(cur[slot[k][0] >> 16], slot[k][0]);
+                    v.y = plane_by_rule(cur[slot[k][1] >> 16], slot[k][1]);
+                    v.z = plane_by_rule(cur[slot[k][2] >> 16], slot[k][2]);
+                    v.w = plane_by_rule(cur[slot[k][3] >> 16], slot[k][3]);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(state) + o);
+                }
+                if (next_state) {
+                    f32x4 v;
+                    v.x = plane_by_rule(nxt[slot[k][0] >> 16], slot[k][0]);
+                    v.y = plane_by_rule(nxt[slot[k][1] >> 16], slot[k][1]);
+                    v.z = plane_by_rule(nxt[slot[k][2] >> 16], slot[k][2]);
+                    v.w = plane_by_rule(nxt[slot[k][3] >> 16], slot[k][3]);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(next_state) + o);
+                }
+            }
+        }
+        __syncthreads();  // the next trip rewrites cur / nxt
+    }
+}
+
 static inline int grid_for(i64 n) {
     i64 b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -276,6 +383,42 @@ static inline int grid_for(i64 n) {
 int launch_traj_pack(int game, const Play& p, i64 n, u8* out, hipStream_t st) {
     if (n <= 0) return AZ_OK;
     AZ_DISPATCH_GAME(game, k_traj_pack<GT><<<dim3(grid_for(n)), dim3(256), 0, st>>>(p, n, out));
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+// TTT / NBTTT: plies before the first 128-byte line of the plane tensors and the ragged tail through the per-float
+// kernel, whole chunks through k_traj_unpack_lines.
+template <class G>
+static int unpack_lines_or_ragged(i64 n, const u8* recs, float* state, float* prob, float* value, i32* winner,
+                                  float* next_state, u8* done, hipStream_t st) {
+    using Geo = UnpackGeo<G>;
+    constexpr int REC = G::W * 8 + G::A * 4 + 4, PL = Geo::PL;
+    auto ragged = [&](i64 lo, i64 m) {
+        if (m <= 0) return;
+        k_traj_unpack<G><<<dim3(grid_for(m * PL)), dim3(256), 0, st>>>(
+            m, recs + lo * REC, state ? state + lo * PL : nullptr, prob ? prob + lo * G::A : nullptr,
+            value ? value + lo : nullptr, winner ? winner + lo : nullptr, next_state ? next_state + lo * PL : nullptr,
+            done ? done + lo : nullptr);
+    };
+    const uintptr_t sa = (uintptr_t)(state ? state : next_state), sb = (uintptr_t)(next_state ? next_state : state);
+    i64 head = n;
+    if (sa && (sa & 127u) == (sb & 127u) && ((uintptr_t)recs & 7u) == 0)
+        for (i64 h = 0; h < 128 && h <= n; h++)
+            if (((sa + (uintptr_t)h * PL * 4) & 127u) == 0) {
+                head = h;
+                break;
+            }
+    const i64 chunks = (n - head) / Geo::CH;
+    ragged(0, head);
+    if (chunks > 0) {
+        const int grid = (int)(chunks < 4096 ? chunks : 4096);
+        k_traj_unpack_lines<G><<<dim3(grid), dim3(256), 0, st>>>(
+            chunks, recs + head * REC, state ? state + head * PL : nullptr, prob ? prob + head * G::A : nullptr,
+            value ? value + head : nullptr, winner ? winner + head : nullptr,
+            next_state ? next_state + head * PL : nullptr, done ? done + head : nullptr);
+    }
+    ragged(head + chunks * Geo::CH, n - head - chunks * Geo::CH);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
@@ -313,6 +456,8 @@ int launch_traj_unpack(int game, i64 n, const u8* recs, float* state, float* pro
         AZ_HIP(hipGetLastError());
         return AZ_OK;
     }
+    if (game == AZ_GAME_TTT) return unpack_lines_or_ragged<TTT>(n, recs, state, prob, value, winner, next_state, done, st);
+    if (game == AZ_GAME_NBTTT) return unpack_lines_or_ragged<NBTTT>(n, recs, state, prob, value, winner, next_state, done, st);
     AZ_DISPATCH_GAME(game, {
         constexpr int PL = GT::GAME == AZ_GAME_C4 ? 126 : (GT::GAME == AZ_GAME_TTT ? 27 : 252);
         k_traj_unpack<GT><<<dim3(grid_for(n * PL)), dim3(256), 0, st>>>(n, recs, state, prob, value, winner, next_state,

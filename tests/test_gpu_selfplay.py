@@ -175,31 +175,34 @@ def test_store_many_equals_per_ply_store(E):
     eng.close()
 
 
-def test_unpack_rows_do_not_depend_on_where_the_ring_pointer_stands(E):
+@pytest.mark.parametrize("game,dims,Gn", [("Connect4", (3, 7, 6, 7), 48), ("TTT", (3, 9, 3, 3), 80),
+                                           ("NBTTT", (28, 9, 3, 3), 16)])
+def test_unpack_rows_do_not_depend_on_where_the_ring_pointer_stands(E, game, dims, Gn):
     """az_traj_unpack_dev peels the plies before the first 128-byte line boundary and the ragged tail off to a
     narrower kernel and streams the middle in 32-ply chunks: whatever row the destination starts at (every residue
     mod 16 moves the boundary) and whatever the count, the rows written are the rows of the pinned case above and
     nothing outside [lo, lo + n) is touched."""
     import torch
     from alphazero_amd.collector import TrajectoryGatherer, store_many
-    eng = E.SelfPlayEngine("Connect4", n_games=48, n_playout=16, evaluator="hash", eval_seed=11, flip="never",
+    eng = E.SelfPlayEngine(game, n_games=Gn, n_playout=16, evaluator="hash", eval_seed=11, flip="never",
                            move="first_max")
-    eng.selfplay(48, temp=1.0, first_n_steps=8)
+    eng.selfplay(Gn, temp=1.0, first_n_steps=8)
     dev = torch.device("cuda", 0)
     recs = TrajectoryGatherer(eng, dev).gather()
     eng.close()
     n = int(recs.shape[0])
-    assert n > 400
-    ref = _RefShapedBuffer(3, n, 7, 6, 7, dev)
-    store_many(ref, recs, "Connect4")
+    assert n > 300
+    C_, A_, H_, W_ = dims
+    ref = _RefShapedBuffer(C_, n, A_, H_, W_, dev)
+    store_many(ref, recs, game)
     names = ("state", "prob", "value", "winner", "next_state", "done")
     for lo, m in [(0, n), (1, n), (3, n - 1), (7, 100), (8, 31), (15, 33), (16, 64), (17, 65), (29, n - 5), (2, 1),
                   (2, 0)]:
-        buf = _RefShapedBuffer(3, n + 64, 7, 6, 7, dev)
+        buf = _RefShapedBuffer(C_, n + 64, A_, H_, W_, dev)
         buf.winner.fill_(-7)
         buf.done.fill_(True)
         buf._ptr = lo
-        store_many(buf, recs[:m], "Connect4")
+        store_many(buf, recs[:m], game)
         assert buf._ptr == lo + m
         for name in names:
             got, want = getattr(buf, name), getattr(ref, name)
