@@ -74,13 +74,15 @@ def _cpu_moves(orc, net, n_playout, budget_s, seed):
     return moves, games + 1, t.stat_playouts
 
 
-def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=8.0):
+def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=None):
     """The CPU oracle (C port of the reference algorithm: sequential single-game MCTS, one batch-1 fp32 CNN forward
     per playout) timed on this box's host on a bounded sample: whole moves of self-play games until the budget is used.
     `value` is ONE thread (what the reference's single-threaded Python loop maps to); `all_cores` runs one
     independent game sequence per core of this job's CPU share (the C calls release the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
+    if multi_budget_s is None:
+        multi_budget_s = 0.55 * budget_s
     net = orc.CNN(blob)
     t0 = time.perf_counter()
     moves, games, sims = _cpu_moves(orc, net, n_playout, budget_s, 0)
@@ -134,7 +136,7 @@ def _box_info(torch, local):
     return info
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
@@ -151,7 +153,7 @@ def main():
     ap.add_argument("--mode", choices=["rolling", "lockstep"], default="rolling",
                     help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
                          "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     import torch.distributed as dist
