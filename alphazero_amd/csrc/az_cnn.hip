@@ -59,6 +59,7 @@ struct Cnn {
     CnnDev d;
     std::vector<void*> allocs;
     CnnW* wino = nullptr;  // the product kernel's weights; null only in the AZ_K3_DIRECT=1 diagnostic mode
+    CnnS* split = nullptr; // AZ_K3_SPLIT=1: the experimental split-fp16 kernel evaluates instead
 };
 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) are far inside the 1e-4 contract.
@@ -457,6 +458,14 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
     }
     Cnn* c = new Cnn();
     memset(&c->d, 0, sizeof(c->d));
+    const char* split = getenv("AZ_K3_SPLIT");  // opt-in experimental kernel (az_cnn_split.hip)
+    if (split && split[0] == '1') {
+        int rcs = cnns_create(blob, n_floats, &c->split);
+        if (rcs != AZ_OK) {
+            delete c;
+            return rcs;
+        }
+    }
     const char* direct = getenv("AZ_K3_DIRECT");  // diagnostic A/B switch; the product kernel is the Winograd form
     if (!(direct && direct[0] == '1')) {
         int rcw = cnnw_create(blob, n_floats, &c->wino);
@@ -535,6 +544,7 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
 void cnn_destroy(Cnn* c) {
     if (!c) return;
     cnnw_destroy(c->wino);
+    cnns_destroy(c->split);
     for (void* q : c->allocs) (void)hipFree(q);
     delete c;
 }
@@ -542,6 +552,7 @@ void cnn_destroy(Cnn* c) {
 int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, float* probs, float* value,
                 hipStream_t st) {
     if (n <= 0) return AZ_OK;
+    if (c->split) return cnns_launch(c->split, (unsigned)n, n, nullptr, nullptr, states_dev, logp, logv, probs, value, st);
     if (c->wino) return cnnw_launch(c->wino, (unsigned)n, n, nullptr, nullptr, states_dev, logp, logv, probs, value, st);
     const unsigned grid = (unsigned)((n + SPB - 1) / SPB);
     k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, n, nullptr, nullptr, states_dev, logp, logv, probs, value);
@@ -550,6 +561,9 @@ int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, 
 }
 
 int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
+    if (c->split)
+        return cnns_launch(c->split, (unsigned)d.gn, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
+                           d.eval_probs, d.eval_value, st);
     if (c->wino)   // the cohort's slots bound its leaf count
         return cnnw_launch(c->wino, (unsigned)d.gn, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
                            d.eval_probs, d.eval_value, st);

@@ -1,6 +1,7 @@
 // az_cnn.hpp -- K3 interface: fused Connect4 policy/value CNN forward on fp32 MFMA.
 //   az_cnn_wino.hip : the product kernel (3x3 convolutions as Winograd F(2x2,3x3) products)
 //   az_cnn.hip      : dispatch + the direct implicit-GEMM kernel (kept for A/B measurement: AZ_K3_DIRECT=1)
+//   az_cnn_split.hip: experimental direct kernel on fp16 MFMA with split fp32 products (opt-in: AZ_K3_SPLIT=1)
 #pragma once
 #include <math.h>
 
@@ -10,6 +11,7 @@ namespace az {
 
 struct Cnn;   // device-resident folded weights of the selected kernel
 struct CnnW;  // Winograd-form weights
+struct CnnS;  // split-fp16 form (experimental, AZ_K3_SPLIT=1)
 
 int cnn_create(const float* blob, size_t n_floats, int max_batch, Cnn** out);
 void cnn_destroy(Cnn* c);
@@ -24,6 +26,11 @@ int cnnw_create(const float* blob, size_t n_floats, CnnW** out);
 void cnnw_destroy(CnnW* c);
 // max_n bounds the batch (grid size); the batch size itself is n_host, or *n_ptr (device) when n_ptr != null.
 int cnnw_launch(CnnW* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
+                float* logv, float* probs, float* value, hipStream_t st);
+
+int cnns_create(const float* blob, size_t n_floats, CnnS** out);
+void cnns_destroy(CnnS* c);
+int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
                 float* logv, float* probs, float* value, hipStream_t st);
 
 // ---- reference state_dict blob walking + eval-mode BatchNorm folding (Network.py:19-24,33-51) ----

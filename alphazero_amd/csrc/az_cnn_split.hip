@@ -1,0 +1,461 @@
+// az_cnn_split.hip -- K3, experimental form (opt-in: AZ_K3_SPLIT=1; the product kernel stays az_cnn_wino.hip).
+//
+// The same network (Connect4/Network.py:19-27,31-51,60-64,78-85; BatchNorm folded) as a DIRECT implicit GEMM on
+// v_mfma_f32_16x16x32_f16, with every fp32 product a*w computed as hi*hi + hi*lo + lo*hi, hi/lo = the fp16 halves of the
+// fp32 operands (22 mantissa bits; the dropped lo*lo term is 2^-22 relative), accumulated in fp32.  Weights are folded
+// in float64, scaled by a power of two per layer (their lo halves stay clear of the fp16 subnormals) and split on the
+// host; the activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
+// image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup of 4 waves; a wave
+// owns 48 cells x all 128 output channels.  The 1x1 convolution of a block chains from the accumulators: the k order
+// of its weights is such that a lane's own 8 accumulator registers of channel fragments 2c and 2c+1 are its B operand
+// for k-slice c.  Measured stand-alone in tools/ubench/block_split_f16.hip; accuracy in tools/split_fp16_accuracy.py.
+#include <string.h>
+
+#include <vector>
+
+#include "az_cnn.hpp"
+
+namespace az {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SCH = 128, SNS = 4;                        // channels, positions per workgroup
+constexpr int SROWS = SNS * 63 + 9 + 20, SRS = SCH + 8;  // padded cells (7 rows x 9 per position, shared zero row) x halves
+constexpr int SFRONT = 10;
+constexpr int SMF = 8, SNF = 3;                          // wave tile: 8 x 16 channels, 3 x 16 cells
+constexpr int SCELLS = SNS * 42;
+constexpr size_t SPLIT_LDS = (size_t)2 * SROWS * SRS * 2;
+
+struct CnnSDev {
+    const f16x8* w_stem;   // [9 tap][8 f][hi|lo][64] : k = channel 8 kg + i (< 3 real)
+    const f16x8* w3[3];    // [36 slice = tap*4 + cs][8 f][hi|lo][64] : k = channel 32 cs + 8 kg + i
+    const f16x8* w1[3];    // [4 c][8 f][hi|lo][64] : chain k order
+    const f16x8* w_head;   // [4 cs][hi|lo][64] : rows 0-2 policy conv, 3 value conv
+    const float *b_stem, *b3[3], *b1[3], *b_head, *plin_w, *plin_b, *vlin_w, *vlin_b;
+    float inv_stem, inv3[3], inv1[3], inv_head;
+};
+struct CnnS {
+    CnnSDev d;
+    std::vector<void*> allocs;
+};
+
+__host__ __device__ inline int scell(int s, int r, int c) { return SFRONT + s * 63 + (r + 1) * 9 + (c + 1); }
+__host__ __device__ inline int chain_k(int c, int kg, int i) { return 32 * c + (i < 4 ? 4 * kg + i : 16 + 4 * kg + (i - 4)); }
+__device__ inline float ssilu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ inline void split8(const f32x4& a, const f32x4& b, f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h[i] = (_Float16)a[i];
+        l[i] = (_Float16)(a[i] - (float)h[i]);
+        h[4 + i] = (_Float16)b[i];
+        l[4 + i] = (_Float16)(b[i] - (float)h[4 + i]);
+    }
+}
+__device__ inline float swave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+#define SMFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+// n_slices k-slices of a 3x3 convolution over the split image: slice sl = tap * per_tap + cs.
+template <int PER_TAP, bool LO_INPUT>
+__device__ inline void conv3x3(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
+                               int lane, f32x4 (&acc)[SMF][SNF]) {
+    constexpr int NSL = 9 * PER_TAP;
+    f16x8 ah[2][SMF], al[2][SMF], bh[2][SNF], bl[2][SNF];
+    auto fetch = [&](int sl, int b) {
+        const int tap = sl / PER_TAP, cs = sl % PER_TAP;
+        const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
+#pragma unroll
+        for (int f = 0; f < SMF; f++) {
+            ah[b][f] = w[((size_t)(sl * SMF + f) * 2 + 0) * 64 + lane];
+            al[b][f] = w[((size_t)(sl * SMF + f) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < SNF; j++) {
+            bh[b][j] = *reinterpret_cast<const f16x8*>(hi + brow[j] + toff);
+            if (LO_INPUT) bl[b][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff);
+        }
+    };
+    auto mfmas = [&](int b) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) {
+                SMFMA(ah[b][f], bh[b][j], acc[f][j]);
+                if (LO_INPUT) SMFMA(ah[b][f], bl[b][j], acc[f][j]);
+                SMFMA(al[b][f], bh[b][j], acc[f][j]);
+            }
+    };
+    fetch(0, 0);
+    for (int sl = 0; sl < NSL; sl += 2) {
+        if (sl + 1 < NSL) fetch(sl + 1, 1);
+        mfmas(0);
+        if (sl + 2 < NSL) fetch(sl + 2, 0);
+        if (sl + 1 < NSL) mfmas(1);
+    }
+}
+
+// v = SiLU(acc * inv + bias) for every (fragment, cell) of this lane -> split -> image, in place
+__device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int g,
+                                   const f32x4 (&val)[SMF][SNF]) {
+#pragma unroll
+    for (int f = 0; f < SMF; f++)
+#pragma unroll
+        for (int j = 0; j < SNF; j++)
+            if (live[j]) {
+                f16x4 oh, ol;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    oh[r] = (_Float16)val[f][j][r];
+                    ol[r] = (_Float16)(val[f][j][r] - (float)oh[r]);
+                }
+                const int at = crow[j] + 16 * f + 4 * g;
+                *reinterpret_cast<f16x4*>(hi + at) = oh;
+                *reinterpret_cast<f16x4*>(lo + at) = ol;
+            }
+}
+
+__global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
+                                                              const u32* __restrict__ list, const u64* __restrict__ states,
+                                                              float* __restrict__ logp, float* __restrict__ logv,
+                                                              float* __restrict__ probs, float* __restrict__ value) {
+    extern __shared__ _Float16 lds[];
+    __shared__ float hb[4][SCELLS];  // head activations: 3 policy channels, 1 value channel
+    __shared__ float s_player[SNS];
+    __shared__ long long s_slot[SNS];
+    _Float16* hi = lds;
+    _Float16* lo = lds + SROWS * SRS;
+    const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
+    const i64 s0 = (i64)blockIdx.x * SNS;
+    if (s0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < SROWS * SRS; i += 256) reinterpret_cast<unsigned*>(lds)[i] = 0u;
+    __syncthreads();
+    // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149): channels 0..2, exact in fp16
+    if (tid < SCELLS) {
+        const int s = tid / 42, q = tid % 42, row = q / 7, col = q % 7;
+        if (s0 + s < n) {
+            const i64 slot = list ? (i64)list[s0 + s] : (s0 + s);
+            const u64 w0 = states[slot * 2], w1 = states[slot * 2 + 1];
+            const int bit = col * 7 + (5 - row);
+            const float vt = (w1 >> 63) ? -1.f : 1.f;
+            _Float16* p = hi + scell(s, row, col) * SRS;
+            p[0] = (_Float16)(float)((w0 >> bit) & 1ull);
+            p[1] = (_Float16)(float)((w1 >> bit) & 1ull);
+            p[2] = (_Float16)vt;
+            if (q == 0) {
+                s_player[s] = vt;
+                s_slot[s] = slot;
+            }
+        }
+    }
+    __syncthreads();
+    int brow[SNF], crow[SNF];
+    bool live[SNF];
+#pragma unroll
+    for (int j = 0; j < SNF; j++) {
+        int col = wave * 48 + j * 16 + n16;
+        live[j] = col < SCELLS;
+        if (!live[j]) col = 0;
+        const int s = col / 42, p = col % 42;
+        crow[j] = scell(s, p / 7, p % 7) * SRS;
+        brow[j] = crow[j] + 8 * g;
+    }
+    f32x4 acc[SMF][SNF];
+    // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
+#pragma unroll
+    for (int f = 0; f < SMF; f++)
+#pragma unroll
+        for (int j = 0; j < SNF; j++) acc[f][j] = (f32x4){0, 0, 0, 0};
+    conv3x3<1, false>(w.w_stem, hi, lo, brow, lane, acc);
+#pragma unroll
+    for (int f = 0; f < SMF; f++) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(w.b_stem + 16 * f + 4 * g);
+#pragma unroll
+        for (int j = 0; j < SNF; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[f][j][r] = ssilu(acc[f][j][r] * w.inv_stem + bb[r]);
+    }
+    __syncthreads();  // every wave has read the input planes
+    store_image(hi, lo, crow, live, g, acc);
+    __syncthreads();
+
+    // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
+    for (int blk = 0; blk < 3; blk++) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) acc[f][j] = (f32x4){0, 0, 0, 0};
+        conv3x3<4, true>(w.w3[blk], hi, lo, brow, lane, acc);
+        f32x4 acc2[SMF][SNF];
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) acc2[f][j] = (f32x4){0, 0, 0, 0};
+        const f16x8* w1 = w.w1[blk];
+        const float* b3 = w.b3[blk];
+        const float inv3 = w.inv3[blk];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            f16x8 th[SNF], tl[SNF], ah[SMF], al[SMF];
+#pragma unroll
+            for (int f = 0; f < SMF; f++) {
+                ah[f] = w1[((size_t)(c * SMF + f) * 2 + 0) * 64 + lane];
+                al[f] = w1[((size_t)(c * SMF + f) * 2 + 1) * 64 + lane];
+            }
+            {  // t = SiLU(conv3x3 + b) for the 32 channels of this k-slice, straight into the split operands
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(b3 + 32 * c + 4 * g);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b3 + 32 * c + 16 + 4 * g);
+#pragma unroll
+                for (int j = 0; j < SNF; j++) {
+                    f32x4 ta, tb;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        ta[r] = ssilu(acc[2 * c][j][r] * inv3 + ba[r]);
+                        tb[r] = ssilu(acc[2 * c + 1][j][r] * inv3 + bb[r]);
+                    }
+                    split8(ta, tb, th[j], tl[j]);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int j = 0; j < SNF; j++) {
+                    SMFMA(ah[f], th[j], acc2[f][j]);
+                    SMFMA(ah[f], tl[j], acc2[f][j]);
+                    SMFMA(al[f], th[j], acc2[f][j]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // every wave is done with the old image as a convolution input
+        {
+            const float* b1 = w.b1[blk];
+            const float inv1 = w.inv1[blk];
+#pragma unroll
+            for (int f = 0; f < SMF; f++) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 16 * f + 4 * g);
+#pragma unroll
+                for (int j = 0; j < SNF; j++) {  // a lane reads only the cells and channels it is about to overwrite
+                    const int at = crow[j] + 16 * f + 4 * g;
+                    const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc2[f][j][r] = ssilu(((float)xh[r] + (float)xl[r]) + (acc2[f][j][r] * inv1 + bb[r]));
+                }
+            }
+            store_image(hi, lo, crow, live, g, acc2);
+        }
+        __syncthreads();
+    }
+
+    // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment
+    {
+        f32x4 ah_[SNF];
+#pragma unroll
+        for (int j = 0; j < SNF; j++) ah_[j] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int cs = 0; cs < 4; cs++) {
+            const f16x8 wh = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane], wl = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < SNF; j++) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(hi + brow[j] + cs * 32);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(lo + brow[j] + cs * 32);
+                SMFMA(wh, bh, ah_[j]);
+                SMFMA(wh, bl, ah_[j]);
+                SMFMA(wl, bh, ah_[j]);
+            }
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < SNF; j++)
+                if (live[j]) {
+                    const int col = wave * 48 + j * 16 + n16;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) hb[r][col] = ssilu(ah_[j][r] * w.inv_head + w.b_head[r]);
+                }
+        }
+    }
+    __syncthreads();
+    // ---- Linear(126->7) / Linear(42->3) + log-softmax + predict() (Network.py:60-64,78-85): wave s, position s
+    const int s = wave;
+    if (s0 + s >= n) return;
+    float pl[7], vl[3];
+#pragma unroll
+    for (int a = 0; a < 7; a++) pl[a] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) vl[k] = 0.f;
+    for (int j = lane; j < 126; j += 64) {  // nn.Flatten of NCHW: index c*42 + h*7 + w
+        const float xv = hb[j / 42][s * 42 + j % 42];
+#pragma unroll
+        for (int a = 0; a < 7; a++) pl[a] += xv * w.plin_w[a * 126 + j];
+    }
+    if (lane < 42) {
+        const float xv = hb[3][s * 42 + lane];
+#pragma unroll
+        for (int k = 0; k < 3; k++) vl[k] += xv * w.vlin_w[k * 42 + lane];
+    }
+#pragma unroll
+    for (int a = 0; a < 7; a++) pl[a] = swave_sum(pl[a]) + w.plin_b[a];
+#pragma unroll
+    for (int k = 0; k < 3; k++) vl[k] = swave_sum(vl[k]) + w.vlin_b[k];
+    if (lane == 0) {
+        const i64 slot = s_slot[s];
+        float mx = pl[0];
+#pragma unroll
+        for (int a = 1; a < 7; a++) mx = fmaxf(mx, pl[a]);
+        float se = 0.f;
+#pragma unroll
+        for (int a = 0; a < 7; a++) se += expf(pl[a] - mx);
+        const float lse = logf(se);
+        const float mv = fmaxf(vl[0], fmaxf(vl[1], vl[2]));
+        const float lsv = logf(expf(vl[0] - mv) + expf(vl[1] - mv) + expf(vl[2] - mv));
+        float vp[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float lv = vl[k] - mv - lsv;
+            if (logv) logv[slot * 3 + k] = lv;
+            vp[k] = expf(lv);
+        }
+#pragma unroll
+        for (int a = 0; a < 7; a++) {
+            const float lp = pl[a] - mx - lse;
+            if (logp) logp[slot * 7 + a] = lp;
+            if (probs) probs[slot * 7 + a] = expf(lp);
+        }
+        // Network.py:83-84: classes [draw, mover wins, mover loses]
+        if (value) value[slot] = (-s_player[s]) * 0.5f * vp[0] + vp[1] - vp[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <class T>
+static int uploads(CnnS* c, const std::vector<T>& v, const T** out) {
+    void* q = nullptr;
+    AZ_HIP(hipMalloc(&q, v.size() * sizeof(T)));
+    c->allocs.push_back(q);
+    AZ_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)q;
+    return AZ_OK;
+}
+
+// One layer's folded weights (float64) -> power-of-two scale, fp16 hi / lo fragments.  `at(frag, lane, i)` gives the
+// folded weight of fragment `frag` (hi and lo copies follow each other), or 0.
+template <class F>
+static float pack_split(int n_frag, F at, std::vector<_Float16>& out) {
+    double mx = 0;
+    for (int fr = 0; fr < n_frag; fr++)
+        for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 8; i++) mx = fmax(mx, fabs(at(fr, l, i)));
+    const double scale = exp2(floor(log2(16384.0 / (mx > 0 ? mx : 1.0))));
+    out.assign((size_t)n_frag * 2 * 64 * 8, (_Float16)0.f);
+    for (int fr = 0; fr < n_frag; fr++)
+        for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 8; i++) {
+                const float v = (float)(at(fr, l, i) * scale);
+                const _Float16 h = (_Float16)v;
+                out[(((size_t)fr * 2 + 0) * 64 + l) * 8 + i] = h;
+                out[(((size_t)fr * 2 + 1) * 64 + l) * 8 + i] = (_Float16)(v - (float)h);
+            }
+    return (float)(1.0 / scale);
+}
+
+int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
+    if (!blob || n_floats != 500106) {
+        set_error("az_net_load: expected 500106 float32 values (the reference CNN state_dict, see include/azamd.h)");
+        return AZ_ERR_ARG;
+    }
+    CnnS* c = new CnnS();
+    memset(&c->d, 0, sizeof(c->d));
+    CnnBlobReader br{blob};
+    int rc = AZ_OK;
+    std::vector<_Float16> pk;
+    auto up16 = [&](const f16x8** dst) {
+        const _Float16* p = nullptr;
+        if (rc == AZ_OK) rc = uploads(c, pk, &p);
+        *dst = reinterpret_cast<const f16x8*>(p);
+    };
+    auto bias_of = [](const CnnBn& b, int n) {
+        std::vector<float> v(n);
+        for (int i = 0; i < n; i++) v[i] = cnn_bn_bias(b, i);
+        return v;
+    };
+    const float* wt = br.take(128 * 3 * 9);
+    CnnBn bn = cnn_take_bn(br, 128);
+    c->d.inv_stem = pack_split(9 * SMF, [&](int fr, int l, int i) {
+        const int tap = fr / SMF, f = fr % SMF, co = 16 * f + l % 16, ci = 8 * (l / 16) + i;
+        return ci < 3 ? (double)wt[((size_t)co * 3 + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co) : 0.0;
+    }, pk);
+    up16(&c->d.w_stem);
+    if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b_stem);
+    for (int b = 0; b < 3; b++) {
+        wt = br.take((size_t)128 * 128 * 9);
+        bn = cnn_take_bn(br, 128);
+        c->d.inv3[b] = pack_split(36 * SMF, [&](int fr, int l, int i) {
+            const int sl = fr / SMF, f = fr % SMF, tap = sl >> 2, cs = sl & 3, co = 16 * f + l % 16, ci = 32 * cs + 8 * (l / 16) + i;
+            return (double)wt[((size_t)co * SCH + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co);
+        }, pk);
+        up16(&c->d.w3[b]);
+        if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b3[b]);
+        wt = br.take((size_t)128 * 128);
+        bn = cnn_take_bn(br, 128);
+        c->d.inv1[b] = pack_split(4 * SMF, [&](int fr, int l, int i) {
+            const int cc = fr / SMF, f = fr % SMF, co = 16 * f + l % 16, ci = chain_k(cc, l / 16, i);
+            return (double)wt[(size_t)co * SCH + ci] * (double)cnn_bn_scale(bn, co);
+        }, pk);
+        up16(&c->d.w1[b]);
+        if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b1[b]);
+    }
+    const float* pconv = br.take(3 * 128);
+    CnnBn pbn = cnn_take_bn(br, 3);
+    const float* plw = br.take(7 * 126);
+    const float* plb = br.take(7);
+    const float* vconv = br.take(128);
+    CnnBn vbn = cnn_take_bn(br, 1);
+    const float* vlw = br.take(3 * 42);
+    const float* vlb = br.take(3);
+    c->d.inv_head = pack_split(4, [&](int cs, int l, int i) {
+        const int row = l % 16, ci = 32 * cs + 8 * (l / 16) + i;
+        if (row < 3) return (double)pconv[row * 128 + ci] * (double)cnn_bn_scale(pbn, row);
+        if (row == 3) return (double)vconv[ci] * (double)cnn_bn_scale(vbn, 0);
+        return 0.0;
+    }, pk);
+    up16(&c->d.w_head);
+    std::vector<float> bh = {cnn_bn_bias(pbn, 0), cnn_bn_bias(pbn, 1), cnn_bn_bias(pbn, 2), cnn_bn_bias(vbn, 0)};
+    if (rc == AZ_OK) rc = uploads(c, bh, &c->d.b_head);
+    if (rc == AZ_OK) rc = uploads(c, std::vector<float>(plw, plw + 7 * 126), &c->d.plin_w);
+    if (rc == AZ_OK) rc = uploads(c, std::vector<float>(plb, plb + 7), &c->d.plin_b);
+    if (rc == AZ_OK) rc = uploads(c, std::vector<float>(vlw, vlw + 3 * 42), &c->d.vlin_w);
+    if (rc == AZ_OK) rc = uploads(c, std::vector<float>(vlb, vlb + 3), &c->d.vlin_b);
+    if (rc == AZ_OK && hipFuncSetAttribute((const void*)k_cnn_forward_split, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)SPLIT_LDS) != hipSuccess) {
+        set_error("hipFuncSetAttribute(k_cnn_forward_split, dynamic LDS) failed");
+        rc = AZ_ERR_HIP;
+    }
+    if (rc != AZ_OK) {
+        cnns_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return AZ_OK;
+}
+
+void cnns_destroy(CnnS* c) {
+    if (!c) return;
+    for (void* q : c->allocs) (void)hipFree(q);
+    delete c;
+}
+
+int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
+                float* logv, float* probs, float* value, hipStream_t st) {
+    const unsigned grid = (max_n + SNS - 1) / SNS;
+    if (grid == 0) return AZ_OK;
+    k_cnn_forward_split<<<dim3(grid), dim3(256), SPLIT_LDS, st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+}  // namespace az

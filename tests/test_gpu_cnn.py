@@ -206,3 +206,40 @@ def test_rolling_selfplay_equals_lockstep(blob, noise):
         assert np.array_equal(t1["z"][i1], t2["z"][i2]), gid
     for k in ("playouts", "leaf_evals", "terminal_hits", "plies", "games_finished", "levels", "children"):
         assert s1[k] == s2[k], (k, s1[k], s2[k])
+
+
+@pytest.fixture()
+def split_eng(blob):
+    """an engine whose network is evaluated by the experimental split-fp16 kernel (az_cnn_split.hip, AZ_K3_SPLIT=1)"""
+    from alphazero_amd.engine import SelfPlayEngine
+    e = SelfPlayEngine("Connect4", n_games=64, n_playout=50, c_puct=1.25, evaluator="cnn", flip="never", reuse_tree=False)
+    os.environ["AZ_K3_SPLIT"] = "1"
+    try:
+        e.load_net(blob)
+    finally:
+        del os.environ["AZ_K3_SPLIT"]
+    yield e
+    e.close()
+
+
+def test_split_fp16_kernel_vs_reference_golden(split_eng, eng, blob):
+    """the opt-in kernel (fp32 products split over fp16 MFMA) against the vectors recorded from the reference, at the
+    SAME tolerance as the product kernel, ragged batches included (4 positions per workgroup), and next to the product
+    kernel's own outputs; a search driven by it finds the same trees' visit totals."""
+    d = np.load(os.path.join(G, "cnn.npz"))
+    envs = [orc.Env.from_cells("Connect4", c) for c in d["cells"]]
+    packed = np.array([e.packed() for e in envs])
+    logp, logv, probs, value = split_eng.net_forward(packed)
+    np.testing.assert_allclose(logp, d["logp"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logv, d["logv"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(probs, d["probs"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(value, d["value"], rtol=1e-4, atol=1e-5)
+    wl, _, wp, wv = eng.net_forward(packed)
+    print("split vs Winograd fp32 kernel: max |dlogp| %.2e, max |dvalue| %.2e" %
+          (np.abs(logp - wl).max(), np.abs(value - wv).max()))
+    for n in (1, 2, 3, 4, 5, 7, 9, 130):
+        lp, lv, pr, va = split_eng.net_forward(packed[:n])
+        assert np.array_equal(lp, logp[:n]) and np.array_equal(va, value[:n])   # batch-composition independence
+    split_eng.search()
+    rc = split_eng.root_children()
+    assert (rc["root_visits"] == 50).all() and (rc["visits"].sum(1) == 49).all()

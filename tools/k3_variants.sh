@@ -11,6 +11,6 @@ for v in ${VARIANTS:-now}; do
   case $v in now) D="-DAZ_K3_DBG_NOW";; nob) D="-DAZ_K3_DBG_NOB";; nowb) D="-DAZ_K3_DBG_NOW -DAZ_K3_DBG_NOB";; *) D=$(echo $v | sed 's/+/ -D/g; s/^/-D/');; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -I../../include $D -c az_cnn.hip -o $OUT/az_cnn_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize -I../../include $D -c az_cnn_wino.hip -o $OUT/az_cnn_wino_$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libazamd_$v.so build/az_tree.o build/az_play.o build/az_env.o build/az_traj.o build/az_engine.o $OUT/az_cnn_$v.o $OUT/az_cnn_wino_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libazamd_$v.so build/az_tree.o build/az_play.o build/az_env.o build/az_traj.o build/az_engine.o build/az_cnn_split.o $OUT/az_cnn_$v.o $OUT/az_cnn_wino_$v.o
 done
 ls -la $OUT/*.so
