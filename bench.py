@@ -47,6 +47,8 @@ EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 # FETCH_SIZE 13544.8 KB x 2 (gfx950 counts 16-byte streaming loads at half their bytes) + WRITE_SIZE 33.4 KB.  It is the
 # 3.4 MB of Winograd-form weights fetched once per XCD L2 per launch; positions in and outputs out are ~25 KB.
 K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi)
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -150,6 +152,11 @@ def main(argv=None):
     ap.add_argument("--cohorts", type=int, default=0, help="slot ranges searched on their own HIP streams (0 = engine default)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event kernel timing in the timed region")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around the tree-step launches too (kernel_time_ms)")
+    ap.add_argument("--k3", choices=["wino", "split"], default="wino",
+                    help="wino: the product kernel (Winograd, fp32 MFMA); split: the experimental kernel (az_cnn_split.hip: "
+                         "fp32 products split over fp16 MFMA, fp32 accumulation)")
+    ap.add_argument("--no-experimental", action="store_true",
+                    help="skip the short extra run that reports the split kernel's rate under `experimental_k3_split_f16`")
     ap.add_argument("--mode", choices=["rolling", "lockstep"], default="rolling",
                     help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
                          "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
@@ -171,10 +178,19 @@ def main(argv=None):
     # creation order, so the engine's stream and its three cohort streams must exist before RCCL and
     # torch.distributed create theirs -- cohort streams that share a queue serialise their K3 launches (measured
     # under torch.distributed.run with the group initialised first: 374 ms per step instead of 280).
-    eng = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
-                         reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
-                         game_id_base=rank * (1 << 40), n_cohorts=args.cohorts)
-    eng.load_net(blob)
+    def make_engine(k3):
+        e = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
+                           reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
+                           game_id_base=rank * (1 << 40), n_cohorts=args.cohorts)
+        if k3 == "split":      # the library reads the switch when the weights are loaded
+            os.environ["AZ_K3_SPLIT"] = "1"
+        try:
+            e.load_net(blob)
+        finally:
+            os.environ.pop("AZ_K3_SPLIT", None)
+        return e
+
+    eng = make_engine(args.k3)
     # under torch.distributed.run (RANK / MASTER_ADDR exported) the RCCL group is set up for any world size, so that a
     # one-rank launch on a one-GPU box walks the same barrier / all-reduce code as the N-GPU job
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
@@ -246,32 +262,43 @@ def main(argv=None):
         # achieved = algorithmic FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the
         # launches do not overlap, i.e. --cohorts 1).
         achieved = FLOP_PER_LEAF * (evals / world) / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
+        if args.k3 == "split":
+            # the split kernel is priced on the pipe it runs on: executed fp16 MFMA flops (3 per algorithmic flop) against
+            # the dense fp16 peak; `algorithmic_tflops` keeps the 41.62 MFLOP-per-leaf figure next to it
+            roof = {"bound": "mfma", "kernel": "k_cnn_forward_split", "achieved": 3 * achieved, "peak": PEAK_F16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                    "algorithmic_tflops": achieved, "executed_flop_per_leaf": SPLIT_FLOP_PER_LEAF,
+                    "algorithm": "direct implicit GEMM on v_mfma_f32_16x16x32_f16; every fp32 product as 3 fp16 products "
+                                 "on split operands, fp32 accumulation"}
+        else:
+            roof = {"bound": "mfma", "kernel": "k_cnn_forward_wino", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
+                    "algorithm": "Winograd F(2x2,3x3) for the 3x3 convolutions; achieved/frac in algorithmic "
+                                 "(direct-convolution) flops, 41.62 MFLOP per leaf",
+                    "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
+                    "executed_frac": achieved * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS}
+        roof.update({"avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch, "launches": cnn["launches"],
+                     "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"], "concurrent_cohorts": eng.n_cohorts,
+                     "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12})
         depth = levels / max(playouts, 1)
         out = {
             "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_all / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.k3 == "wino" else "f32 (products as 3 x f16 MFMA on split operands, f32 accumulation)",
+            "data": "synthetic",
             "sims_per_sec": playouts / dt_all,
             "config": {"workload": "Connect4 CNN self-play, %d concurrent games/GPU x %d playouts/move, real "
                                    "AZ_Connect4_CNN_current weights, Dirichlet 0.7, random flips, tree reuse "
                                    "(BASELINE configs[2]%s)" % (G, S, "; trajectories all-gathered over RCCL into "
                                                                 "ReplayBuffer tensors" if world > 1 else ""),
-                       "mode": args.mode, "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
+                       "mode": args.mode, "k3": args.k3, "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
                        "games_finished_in_window": finished, "slot_plies_in_window": plies,
                        "leaf_evals": evals, "terminal_hits": term, "mean_tree_depth": depth,
                        "plies_stored_in_replay": sink.total_stored - stored0,
                        "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
-            "roofline": {"bound": "mfma", "kernel": "k_cnn_forward_wino", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
-                         "avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch,
-                         "launches": cnn["launches"], "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"],
-                         "concurrent_cohorts": eng.n_cohorts,
-                         "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12,
-                         "algorithm": "Winograd F(2x2,3x3) for the 3x3 convolutions; achieved/frac in algorithmic "
-                                      "(direct-convolution) flops, 41.62 MFLOP per leaf",
-                         "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
-                         "executed_frac": achieved * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS},
+            "roofline": roof,
             "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
             "box": _box_info(torch, local),
         }
@@ -280,6 +307,27 @@ def main(argv=None):
             out["config"]["x_cpu_port_1core"] = games_s / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["config"]["x_cpu_port_all_cores"] = games_s / out["cpu_baseline"]["all_cores"]["value"]
+        if world == 1 and args.k3 == "wino" and not args.no_experimental:
+            # the experimental K3 (opt-in, not the headline): the same workload for a short window on a second engine
+            eng.close()
+            eng = make_engine("split")
+            gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
+            x_steps = max(6, args.steps // 2)
+            for _ in range(max(2, args.warmup)):
+                one_step()
+            eng.reset_stats()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(x_steps):
+                one_step()
+            barrier()
+            xdt = time.perf_counter() - t0
+            xst = eng.stats()
+            out["experimental_k3_split_f16"] = {
+                "value": (xst["plies"] / xdt) / mean_len, "unit": "games/s", "sims_per_sec": xst["playouts"] / xdt,
+                "steps": x_steps, "ms_per_step": xdt / x_steps * 1e3, "switch": "AZ_K3_SPLIT=1 / bench.py --k3 split",
+                "note": "az_cnn_split.hip: fp32 products as 3 fp16 MFMA products on split operands, fp32 accumulation; "
+                        "same parity tests and tolerance as the product kernel; not the headline value"}
         print(json.dumps(out))
     eng.close()
     if use_dist:

@@ -87,6 +87,35 @@ def main():
         for l in open(os.path.join(O, "tree_stats.log")):
             if not re.match(r"^[WEI]\d{8}", l) and "amdgpu.ids" not in l:
                 f.write(l)
+    # 4. the experimental split-fp16 K3 (tools/gpu_profile_split.sh), when its passes exist
+    OS = O + "_split"
+    if os.path.isdir(OS):
+        KS = "k_cnn_forward_split"
+        with open(os.path.join(P, R + "_k3_split.txt"), "w") as f:
+            f.write("# experimental K3 %s (az_cnn_split.hip, AZ_K3_SPLIT=1 / bench.py --k3 split): fp32 products as 3 fp16 MFMA "
+                    "products on split operands, fp32 accumulation\n" % KS)
+            f.write("## rocprofv3 --kernel-trace --stats -- python3 bench.py --k3 split --steps 4 --warmup 1 --no-cpu-baseline "
+                    "--mean-plies 33.27\n")
+            f.write(cap(rs.kernel_stats, os.path.join(OS, "bench", "bench_results.db")))
+            f.write("## bench.py JSON line of that run:\n")
+            f.write(open(os.path.join(OS, "bench_line.json")).read())
+            f.write("## PMC passes on AZ_K3_SPLIT=1 tools/k3_sweep.py 6144 (K3 alone, 1536 workgroups of 4 leaves per launch)\n")
+            for p_ in ("k3_mfma", "k3_fetch", "k3_write"):
+                f.write("### %s\n" % p_)
+                f.write("\n".join(l for l in cap(rs.pmc_stats, os.path.join(OS, p_, "pmc_results.db")).split("\n")
+                                  if "cnn" in l or l.startswith("kernel")) + "\n")
+                for l in open(os.path.join(OS, p_ + ".log")):
+                    if l.startswith("n="):
+                        f.write(l)
+            db = os.path.join(OS, "k3_mfma", "pmc_results.db")
+            gui, dur, _ = pmc_mean(db, KS, "GRBM_GUI_ACTIVE")
+            busy = pmc_mean(db, KS, "SQ_VALU_MFMA_BUSY_CYCLES")[0]
+            cyc = gui / 8.0
+            f.write("# derived: effective clock = GRBM_GUI_ACTIVE/8/duration = %.3f GHz; MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                    "(1024 SIMDs x %.0f cycles) = %.3f\n" % (cyc / (dur / 1e3) / 1e3, cyc, busy / (1024 * cyc)))
+            kf = pmc_mean(os.path.join(OS, "k3_fetch", "pmc_results.db"), KS, "FETCH_SIZE")
+            kw = pmc_mean(os.path.join(OS, "k3_write", "pmc_results.db"), KS, "WRITE_SIZE")
+            f.write("# derived: HBM traffic per launch = 2 x %.0f KB + %.0f KB = %.1f MB\n" % (kf[0], kw[0], (2 * kf[0] + kw[0]) / 1024))
     print("wrote profiles/%s_*.txt" % R)
 
 
