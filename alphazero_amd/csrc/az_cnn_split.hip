@@ -80,15 +80,21 @@ __device__ inline void conv3x3(const f16x8* __restrict__ w, const _Float16* hi, 
             if (LO_INPUT) bl[b][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff);
         }
     };
-    auto mfmas = [&](int b) {
+    auto mfmas = [&](int b) {  // product by product: 24 independent accumulators between two uses of the same one
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
-            for (int j = 0; j < SNF; j++) {
-                SMFMA(ah[b][f], bh[b][j], acc[f][j]);
-                if (LO_INPUT) SMFMA(ah[b][f], bl[b][j], acc[f][j]);
-                SMFMA(al[b][f], bh[b][j], acc[f][j]);
-            }
+            for (int j = 0; j < SNF; j++) SMFMA(ah[b][f], bh[b][j], acc[f][j]);
+        if (LO_INPUT) {
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int j = 0; j < SNF; j++) SMFMA(ah[b][f], bl[b][j], acc[f][j]);
+        }
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) SMFMA(al[b][f], bh[b][j], acc[f][j]);
     };
     fetch(0, 0);
     for (int sl = 0; sl < NSL; sl += 2) {
@@ -224,11 +230,15 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
 #pragma unroll
             for (int f = 0; f < SMF; f++)
 #pragma unroll
-                for (int j = 0; j < SNF; j++) {
-                    SMFMA(ah[f], th[j], acc2[f][j]);
-                    SMFMA(ah[f], tl[j], acc2[f][j]);
-                    SMFMA(al[f], th[j], acc2[f][j]);
-                }
+                for (int j = 0; j < SNF; j++) SMFMA(ah[f], th[j], acc2[f][j]);
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int j = 0; j < SNF; j++) SMFMA(ah[f], tl[j], acc2[f][j]);
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int j = 0; j < SNF; j++) SMFMA(al[f], th[j], acc2[f][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // every wave is done with the old image as a convolution input
