@@ -224,6 +224,9 @@ int az_traj_unpack_dev(int game, int64_t n, const void *packed_dev, float *state
 /* ---- K3: network --------------------------------------------------------------------------------------- */
 /* Upload the Connect4 CNN (Connect4/Network.py:30-55).  blob = every float32 tensor of the reference
  * state_dict concatenated in state_dict order (500106 floats); BatchNorm (eval) is folded here. */
+/* Environment switches read here (diagnostics / experiments, not part of the contract): AZ_K3_DIRECT=1 evaluates with the
+ * direct fp32 implicit-GEMM kernel instead of the Winograd one; AZ_K3_SPLIT=1 with the experimental kernel that computes
+ * every fp32 product as three fp16 MFMA products on split operands (fp32 accumulation). */
 int az_net_load(az_engine *e, const float *blob, size_t n_floats);
 /* CNN.forward + predict (Network.py:60-64,78-85) for n packed Connect4 positions:
  * logp [n][7], logv [n][3], probs [n][7], value [n].  Any output may be NULL. */
