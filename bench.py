@@ -312,8 +312,8 @@ def main(argv=None):
             eng.close()
             eng = make_engine("split")
             gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
-            x_steps = max(6, args.steps // 2)
-            for _ in range(max(2, args.warmup)):
+            x_steps = args.steps          # the same window as the headline run
+            for _ in range(args.warmup):
                 one_step()
             eng.reset_stats()
             barrier()
