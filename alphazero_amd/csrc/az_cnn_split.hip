@@ -24,7 +24,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int SCH = 128, SNS = 4;                        // channels, positions per workgroup
 constexpr int SROWS = SNS * 63 + 9 + 20, SRS = SCH + 8;  // padded cells (7 rows x 9 per position, shared zero row) x halves
 constexpr int SFRONT = 10;
-constexpr int SMF = 8, SNF = 3;                          // wave tile: 8 x 16 channels, 3 x 16 cells
+constexpr int SMF = 4, SNF = 6;                          // wave tile: 4 x 16 channels, 6 x 16 cells (2 x 2 waves)
+constexpr int SMFT = 8;                                  // channel fragments in all
 constexpr int SCELLS = SNS * 42;
 constexpr size_t SPLIT_LDS = (size_t)2 * SROWS * SRS * 2;
 
@@ -60,19 +61,22 @@ __device__ inline float swave_sum(float v) {
 }
 #define SMFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
-// n_slices k-slices of a 3x3 convolution over the split image: slice sl = tap * per_tap + cs.
-template <int PER_TAP, bool LO_INPUT>
-__device__ inline void conv3x3(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
-                               int lane, f32x4 (&acc)[SMF][SNF]) {
-    constexpr int NSL = 9 * PER_TAP;
+// A convolution over the split image as 9 (3x3) or 1 (1x1) taps x PER_TAP k-slices of 32 channels; slice sl = tap * PER_TAP
+// + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
+// from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
+// 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
+template <int TAPS, int PER_TAP, bool LO_INPUT>
+__device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
+                                  int lane, int fbase, f32x4 (&acc)[SMF][SNF]) {
+    constexpr int NSL = TAPS * PER_TAP;
     f16x8 ah[2][SMF], al[2][SMF], bh[2][SNF], bl[2][SNF];
     auto fetch = [&](int sl, int b) {
-        const int tap = sl / PER_TAP, cs = sl % PER_TAP;
+        const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
         const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
 #pragma unroll
         for (int f = 0; f < SMF; f++) {
-            ah[b][f] = w[((size_t)(sl * SMF + f) * 2 + 0) * 64 + lane];
-            al[b][f] = w[((size_t)(sl * SMF + f) * 2 + 1) * 64 + lane];
+            ah[b][f] = w[((size_t)(sl * SMFT + fbase + f) * 2 + 0) * 64 + lane];
+            al[b][f] = w[((size_t)(sl * SMFT + fbase + f) * 2 + 1) * 64 + lane];
         }
 #pragma unroll
         for (int j = 0; j < SNF; j++) {
@@ -106,7 +110,7 @@ __device__ inline void conv3x3(const f16x8* __restrict__ w, const _Float16* hi, 
 }
 
 // v = SiLU(acc * inv + bias) for every (fragment, cell) of this lane -> split -> image, in place
-__device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int g,
+__device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int ch0,
                                    const f32x4 (&val)[SMF][SNF]) {
 #pragma unroll
     for (int f = 0; f < SMF; f++)
@@ -119,7 +123,7 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
                     oh[r] = (_Float16)val[f][j][r];
                     ol[r] = (_Float16)(val[f][j][r] - (float)oh[r]);
                 }
-                const int at = crow[j] + 16 * f + 4 * g;
+                const int at = crow[j] + ch0 + 16 * f;
                 *reinterpret_cast<f16x4*>(hi + at) = oh;
                 *reinterpret_cast<f16x4*>(lo + at) = ol;
             }
@@ -160,11 +164,13 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         }
     }
     __syncthreads();
+    // wave (wa, wb): channels 64 wa .. 64 wa + 63 (fragments 4 wa .. 4 wa + 3) x cells 96 wb .. 96 wb + 95
+    const int wa = wave & 1, wb = wave >> 1, fbase = 4 * wa, ch0 = 64 * wa + 4 * g;
     int brow[SNF], crow[SNF];
     bool live[SNF];
 #pragma unroll
     for (int j = 0; j < SNF; j++) {
-        int col = wave * 48 + j * 16 + n16;
+        int col = wb * 96 + j * 16 + n16;
         live[j] = col < SCELLS;
         if (!live[j]) col = 0;
         const int s = col / 42, p = col % 42;
@@ -172,98 +178,64 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         brow[j] = crow[j] + 8 * g;
     }
     f32x4 acc[SMF][SNF];
+    auto zero = [&](f32x4 (&a)[SMF][SNF]) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) a[f][j] = (f32x4){0, 0, 0, 0};
+    };
+    // a = SiLU(a * inv + bias[channel]) (+ res)
+    auto activate = [&](f32x4 (&a)[SMF][SNF], const float* bias, float inv, const f32x4 (*res)[SNF]) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ch0 + 16 * f);
+#pragma unroll
+            for (int j = 0; j < SNF; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = a[f][j][r] * inv + bb[r];
+                    if (res) v += res[f][j][r];
+                    a[f][j][r] = ssilu(v);
+                }
+        }
+    };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
-#pragma unroll
-    for (int f = 0; f < SMF; f++)
-#pragma unroll
-        for (int j = 0; j < SNF; j++) acc[f][j] = (f32x4){0, 0, 0, 0};
-    conv3x3<1, false>(w.w_stem, hi, lo, brow, lane, acc);
-#pragma unroll
-    for (int f = 0; f < SMF; f++) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(w.b_stem + 16 * f + 4 * g);
-#pragma unroll
-        for (int j = 0; j < SNF; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[f][j][r] = ssilu(acc[f][j][r] * w.inv_stem + bb[r]);
-    }
+    zero(acc);
+    conv_split<9, 1, false>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    activate(acc, w.b_stem, w.inv_stem, nullptr);
     __syncthreads();  // every wave has read the input planes
-    store_image(hi, lo, crow, live, g, acc);
+    store_image(hi, lo, crow, live, ch0, acc);
     __syncthreads();
 
     // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
     for (int blk = 0; blk < 3; blk++) {
+        f32x4 xres[SMF][SNF];  // this lane's own entries of x, kept for the residual while the image holds t
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
-            for (int j = 0; j < SNF; j++) acc[f][j] = (f32x4){0, 0, 0, 0};
-        conv3x3<4, true>(w.w3[blk], hi, lo, brow, lane, acc);
-        f32x4 acc2[SMF][SNF];
+            for (int j = 0; j < SNF; j++) {
+                const int at = crow[j] + ch0 + 16 * f;
+                const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
 #pragma unroll
-        for (int f = 0; f < SMF; f++)
-#pragma unroll
-            for (int j = 0; j < SNF; j++) acc2[f][j] = (f32x4){0, 0, 0, 0};
-        const f16x8* w1 = w.w1[blk];
-        const float* b3 = w.b3[blk];
-        const float inv3 = w.inv3[blk];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            f16x8 th[SNF], tl[SNF], ah[SMF], al[SMF];
-#pragma unroll
-            for (int f = 0; f < SMF; f++) {
-                ah[f] = w1[((size_t)(c * SMF + f) * 2 + 0) * 64 + lane];
-                al[f] = w1[((size_t)(c * SMF + f) * 2 + 1) * 64 + lane];
+                for (int r = 0; r < 4; r++) xres[f][j][r] = (float)xh[r] + (float)xl[r];
             }
-            {  // t = SiLU(conv3x3 + b) for the 32 channels of this k-slice, straight into the split operands
-                const f32x4 ba = *reinterpret_cast<const f32x4*>(b3 + 32 * c + 4 * g);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b3 + 32 * c + 16 + 4 * g);
-#pragma unroll
-                for (int j = 0; j < SNF; j++) {
-                    f32x4 ta, tb;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        ta[r] = ssilu(acc[2 * c][j][r] * inv3 + ba[r]);
-                        tb[r] = ssilu(acc[2 * c + 1][j][r] * inv3 + bb[r]);
-                    }
-                    split8(ta, tb, th[j], tl[j]);
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < SMF; f++)
-#pragma unroll
-                for (int j = 0; j < SNF; j++) SMFMA(ah[f], th[j], acc2[f][j]);
-#pragma unroll
-            for (int f = 0; f < SMF; f++)
-#pragma unroll
-                for (int j = 0; j < SNF; j++) SMFMA(ah[f], tl[j], acc2[f][j]);
-#pragma unroll
-            for (int f = 0; f < SMF; f++)
-#pragma unroll
-                for (int j = 0; j < SNF; j++) SMFMA(al[f], th[j], acc2[f][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();  // every wave is done with the old image as a convolution input
-        {
-            const float* b1 = w.b1[blk];
-            const float inv1 = w.inv1[blk];
-#pragma unroll
-            for (int f = 0; f < SMF; f++) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 16 * f + 4 * g);
-#pragma unroll
-                for (int j = 0; j < SNF; j++) {  // a lane reads only the cells and channels it is about to overwrite
-                    const int at = crow[j] + 16 * f + 4 * g;
-                    const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        acc2[f][j][r] = ssilu(((float)xh[r] + (float)xl[r]) + (acc2[f][j][r] * inv1 + bb[r]));
-                }
-            }
-            store_image(hi, lo, crow, live, g, acc2);
-        }
+        zero(acc);
+        conv_split<9, 4, true>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        activate(acc, w.b3[blk], w.inv3[blk], nullptr);
+        __syncthreads();  // every wave is done with x as a convolution input
+        store_image(hi, lo, crow, live, ch0, acc);  // t
+        __syncthreads();
+        zero(acc);
+        conv_split<1, 4, true>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        activate(acc, w.b1[blk], w.inv1[blk], xres);
+        __syncthreads();  // every wave is done with t
+        store_image(hi, lo, crow, live, ch0, acc);
         __syncthreads();
     }
 
-    // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment
-    {
+    // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment; the waves
+    // with wa == 0 do it for their cells
+    if (wa == 0) {
         f32x4 ah_[SNF];
 #pragma unroll
         for (int j = 0; j < SNF; j++) ah_[j] = (f32x4){0, 0, 0, 0};
@@ -283,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
 #pragma unroll
             for (int j = 0; j < SNF; j++)
                 if (live[j]) {
-                    const int col = wave * 48 + j * 16 + n16;
+                    const int col = wb * 96 + j * 16 + n16;
 #pragma unroll
                     for (int r = 0; r < 4; r++) hb[r][col] = ssilu(ah_[j][r] * w.inv_head + w.b_head[r]);
                 }
@@ -395,8 +367,8 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     };
     const float* wt = br.take(128 * 3 * 9);
     CnnBn bn = cnn_take_bn(br, 128);
-    c->d.inv_stem = pack_split(9 * SMF, [&](int fr, int l, int i) {
-        const int tap = fr / SMF, f = fr % SMF, co = 16 * f + l % 16, ci = 8 * (l / 16) + i;
+    c->d.inv_stem = pack_split(9 * SMFT, [&](int fr, int l, int i) {
+        const int tap = fr / SMFT, f = fr % SMFT, co = 16 * f + l % 16, ci = 8 * (l / 16) + i;
         return ci < 3 ? (double)wt[((size_t)co * 3 + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co) : 0.0;
     }, pk);
     up16(&c->d.w_stem);
@@ -404,16 +376,16 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     for (int b = 0; b < 3; b++) {
         wt = br.take((size_t)128 * 128 * 9);
         bn = cnn_take_bn(br, 128);
-        c->d.inv3[b] = pack_split(36 * SMF, [&](int fr, int l, int i) {
-            const int sl = fr / SMF, f = fr % SMF, tap = sl >> 2, cs = sl & 3, co = 16 * f + l % 16, ci = 32 * cs + 8 * (l / 16) + i;
+        c->d.inv3[b] = pack_split(36 * SMFT, [&](int fr, int l, int i) {
+            const int sl = fr / SMFT, f = fr % SMFT, tap = sl >> 2, cs = sl & 3, co = 16 * f + l % 16, ci = 32 * cs + 8 * (l / 16) + i;
             return (double)wt[((size_t)co * SCH + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w3[b]);
         if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b3[b]);
         wt = br.take((size_t)128 * 128);
         bn = cnn_take_bn(br, 128);
-        c->d.inv1[b] = pack_split(4 * SMF, [&](int fr, int l, int i) {
-            const int cc = fr / SMF, f = fr % SMF, co = 16 * f + l % 16, ci = chain_k(cc, l / 16, i);
+        c->d.inv1[b] = pack_split(4 * SMFT, [&](int fr, int l, int i) {
+            const int cc = fr / SMFT, f = fr % SMFT, co = 16 * f + l % 16, ci = 32 * cc + 8 * (l / 16) + i;
             return (double)wt[(size_t)co * SCH + ci] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w1[b]);

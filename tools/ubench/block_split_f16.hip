@@ -41,7 +41,7 @@ __device__ inline void split8(const f32x4& a, const f32x4& b, f16x8& h, f16x8& l
 __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, const f16x8* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ b2,
                                                   const float* __restrict__ x, float* __restrict__ y, float inv_s3, float inv_s1,
-                                                  unsigned long long* cyc) {
+                                                  unsigned long long* cyc, unsigned long long* phase) {
     extern __shared__ _Float16 lds[];
     _Float16* hi = lds;
     _Float16* lo = lds + ROWS * RS;
@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, 
         brow[j] = crow[j] + 8 * g;
     }
     const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tp = t0;
+#define STAMP(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[i] += tn_ - tp; tp = tn_; }
     for (int round = 0; round < ROUNDS; round++) {
         // the real kernel has other weights in every block: keep the compiler from hoisting these rounds' common loads
         asm volatile("" : "+s"(w1), "+s"(w3), "+s"(b1), "+s"(b2));
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, 
                 mfmas(1);
             }
         }
+        STAMP(0);
         // ---- 1x1 convolution chained from the registers
         f32x4 acc2[MF][NF];
 #pragma unroll
@@ -150,9 +153,11 @@ __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, 
                 }
             __builtin_amdgcn_sched_barrier(0);  // keep the next slice's 16 weight fragments from being hoisted up here
         }
+        STAMP(1);
         // ---- out = SiLU(x + conv1x1 + b2): residual from the split image (a lane reads only the cells and channels it
         // is about to overwrite), result split again and written in place once every wave is done with the old image
         __syncthreads();
+        STAMP(2);
 #pragma unroll
         for (int f = 0; f < MF; f++) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + 16 * f + 4 * g);
@@ -174,7 +179,9 @@ __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, 
                 }
             }
         }
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
         if (round == ROUNDS - 1) {
             float* yb = y + (size_t)blockIdx.x * NS * 42 * CH;
 #pragma unroll
@@ -189,7 +196,10 @@ __global__ __launch_bounds__(256, 1) void k_block(const f16x8* __restrict__ w3, 
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    if (tid == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    if (tid == 0 && blockIdx.x == 0) {
+        *cyc = t1 - t0;
+        for (int i = 0; i < 5; i++) phase[i] = ph[i];
+    }
 }
 
 #define CK(x)                                                     \
@@ -240,7 +250,8 @@ int main() {
                 }
     f16x8 *d3, *d1;
     float *db1, *db2, *dx, *dy;
-    unsigned long long* dc;
+    unsigned long long *dc, *dph;
+    CK(hipMalloc(&dph, 40));
     CK(hipMalloc(&d3, p3.size() * 2));
     CK(hipMalloc(&d1, p1.size() * 2));
     CK(hipMalloc(&db1, CH * 4));
@@ -261,7 +272,7 @@ int main() {
     float ms = 0;
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0));
-        k_block<<<WG, 256, smem>>>(d3, d1, db1, db2, dx, dy, 1.0f / s3, 1.0f / s1, dc);
+        k_block<<<WG, 256, smem>>>(d3, d1, db1, db2, dx, dy, 1.0f / s3, 1.0f / s1, dc, dph);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -269,6 +280,10 @@ int main() {
     CK(hipGetLastError());
     unsigned long long c = 0;
     CK(hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost));
+    unsigned long long ph[5];
+    CK(hipMemcpy(ph, dph, 40, hipMemcpyDeviceToHost));
+    printf("phases per block (k cycles, wave 0): 3x3 conv %.1f | SiLU + split + chained 1x1 %.1f | barrier wait %.1f | residual + SiLU + split + store %.1f | barrier wait %.1f\n",
+           ph[0] / 1e3 / ROUNDS, ph[1] / 1e3 / ROUNDS, ph[2] / 1e3 / ROUNDS, ph[3] / 1e3 / ROUNDS, ph[4] / 1e3 / ROUNDS);
     std::vector<float> yh((size_t)NS * 42 * CH);
     CK(hipMemcpy(yh.data(), dy, yh.size() * 4, hipMemcpyDeviceToHost));
     // float64 reference for workgroup 0: ROUNDS blocks in a row
