@@ -5,10 +5,11 @@
 // fp32 operands (22 mantissa bits; the dropped lo*lo term is 2^-22 relative), accumulated in fp32.  Weights are folded
 // in float64, scaled by a power of two per layer (their lo halves stay clear of the fp16 subnormals) and split on the
 // host; the activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
-// image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup of 4 waves; a wave
-// owns 48 cells x all 128 output channels.  The 1x1 convolution of a block chains from the accumulators: the k order
-// of its weights is such that a lane's own 8 accumulator registers of channel fragments 2c and 2c+1 are its B operand
-// for k-slice c.  Measured stand-alone in tools/ubench/block_split_f16.hip; accuracy in tools/split_fp16_accuracy.py.
+// image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup; its 4 waves are a
+// 2 x 2 grid, a wave owns 64 output channels x 96 cells.  Inside a residual block a lane keeps its own entries of x in
+// registers for the residual, t = SiLU(BN(conv3x3(x))) goes through the image and the 1x1 convolution is the same
+// routine with one tap.  Prototypes and measurements: tools/ubench/{conv,block}_split_f16.hip, tools/k3_accuracy.py,
+// tools/split_fp16_accuracy.py; DESIGN.md section 8.
 #include <string.h>
 
 #include <vector>
@@ -32,7 +33,7 @@ constexpr size_t SPLIT_LDS = (size_t)2 * SROWS * SRS * 2;
 struct CnnSDev {
     const f16x8* w_stem;   // [9 tap][8 f][hi|lo][64] : k = channel 8 kg + i (< 3 real)
     const f16x8* w3[3];    // [36 slice = tap*4 + cs][8 f][hi|lo][64] : k = channel 32 cs + 8 kg + i
-    const f16x8* w1[3];    // [4 c][8 f][hi|lo][64] : chain k order
+    const f16x8* w1[3];    // [4 cs][8 f][hi|lo][64] : k = channel 32 cs + 8 kg + i
     const f16x8* w_head;   // [4 cs][hi|lo][64] : rows 0-2 policy conv, 3 value conv
     const float *b_stem, *b3[3], *b1[3], *b_head, *plin_w, *plin_b, *vlin_w, *vlin_b;
     float inv_stem, inv3[3], inv1[3], inv_head;
@@ -43,17 +44,7 @@ struct CnnS {
 };
 
 __host__ __device__ inline int scell(int s, int r, int c) { return SFRONT + s * 63 + (r + 1) * 9 + (c + 1); }
-__host__ __device__ inline int chain_k(int c, int kg, int i) { return 32 * c + (i < 4 ? 4 * kg + i : 16 + 4 * kg + (i - 4)); }
 __device__ inline float ssilu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ inline void split8(const f32x4& a, const f32x4& b, f16x8& h, f16x8& l) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        h[i] = (_Float16)a[i];
-        l[i] = (_Float16)(a[i] - (float)h[i]);
-        h[4 + i] = (_Float16)b[i];
-        l[4 + i] = (_Float16)(b[i] - (float)h[4 + i]);
-    }
-}
 __device__ inline float swave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
