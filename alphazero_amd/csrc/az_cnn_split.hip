@@ -1,7 +1,7 @@
 // az_cnn_split.hip -- K3, experimental form (opt-in: AZ_K3_SPLIT=1; the product kernel stays az_cnn_wino.hip).
 //
 // The same network (Connect4/Network.py:19-27,31-51,60-64,78-85; BatchNorm folded) as a DIRECT implicit GEMM on
-// v_mfma_f32_16x16x32_f16, with every fp32 product a*w computed as hi*hi + hi*lo + lo*hi, hi/lo = the fp16 halves of the
+// fp16 MFMA (v_mfma_f32_32x32x16_f16 in the tile loops), with every fp32 product a*w computed as hi*hi + hi*lo + lo*hi, hi/lo = the fp16 halves of the
 // fp32 operands (22 mantissa bits; the dropped lo*lo term is 2^-22 relative), accumulated in fp32.  Weights are folded
 // in float64, scaled by a power of two per layer (their lo halves stay clear of the fp16 subnormals) and split on the
 // host; the activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
@@ -19,21 +19,24 @@
 namespace az {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SCH = 128, SNS = 4;                        // channels, positions per workgroup
 constexpr int SROWS = SNS * 63 + 9 + 20, SRS = SCH + 8;  // padded cells (7 rows x 9 per position, shared zero row) x halves
 constexpr int SFRONT = 10;
-constexpr int SMF = 4, SNF = 6;                          // wave tile: 4 x 16 channels, 6 x 16 cells (2 x 2 waves)
-constexpr int SMFT = 8;                                  // channel fragments in all
+constexpr int SMF = 2, SNF = 3;                          // wave tile: 2 x 32 channels, 3 x 32 cells (2 x 2 waves)
+constexpr int SMFT = 4;                                  // 32-channel fragments in all
 constexpr int SCELLS = SNS * 42;
 constexpr size_t SPLIT_LDS = (size_t)2 * SROWS * SRS * 2;
 
 struct CnnSDev {
-    const f16x8* w_stem;   // [9 tap][8 f][hi|lo][64] : k = channel 8 kg + i (< 3 real)
-    const f16x8* w3[3];    // [36 slice = tap*4 + cs][8 f][hi|lo][64] : k = channel 32 cs + 8 kg + i
-    const f16x8* w1[3];    // [4 cs][8 f][hi|lo][64] : k = channel 32 cs + 8 kg + i
+    // tile weights, 32x32x16 fragments: [slice][kh][4 F][hi|lo][64 lanes] f16x8, lane = (channel 32 F + lane % 32,
+    // k = channel 32 cs + 16 kh + 8 (lane / 32) + i)
+    const f16x8* w_stem;   // 9 slices (tap), channels 0..2 real
+    const f16x8* w3[3];    // 36 slices = tap * 4 + cs
+    const f16x8* w1[3];    // 4 slices = cs
     const f16x8* w_head;   // [4 cs][hi|lo][64] : rows 0-2 policy conv, 3 value conv
     const float *b_stem, *b3[3], *b1[3], *b_head, *plin_w, *plin_b, *vlin_w, *vlin_b;
     float inv_stem, inv3[3], inv1[3], inv_head;
@@ -50,7 +53,8 @@ __device__ inline float swave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-#define SMFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define SMFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)      // the tile loops
+#define SMFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)    // the heads
 
 // A convolution over the split image as 9 (3x3) or 1 (1x1) taps x PER_TAP k-slices of 32 channels; slice sl = tap * PER_TAP
 // + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
@@ -58,38 +62,45 @@ __device__ inline float swave_sum(float v) {
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
 template <int TAPS, int PER_TAP, bool LO_INPUT>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
-                                  int lane, int fbase, f32x4 (&acc)[SMF][SNF]) {
+                                  int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
-    f16x8 ah[2][SMF], al[2][SMF], bh[2][SNF], bl[2][SNF];
+    // v_mfma_f32_32x32x16_f16: a slice of 32 channels is two k-steps of 16 (kh); A = 32 channels x 16 k, B = 16 k x 32 cells
+    f16x8 ah[2][2][SMF], al[2][2][SMF], bh[2][2][SNF], bl[2][2][SNF];
     auto fetch = [&](int sl, int b) {
         const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
         const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
 #pragma unroll
-        for (int f = 0; f < SMF; f++) {
-            ah[b][f] = w[((size_t)(sl * SMFT + fbase + f) * 2 + 0) * 64 + lane];
-            al[b][f] = w[((size_t)(sl * SMFT + fbase + f) * 2 + 1) * 64 + lane];
-        }
+        for (int kh = 0; kh < 2; kh++) {
 #pragma unroll
-        for (int j = 0; j < SNF; j++) {
-            bh[b][j] = *reinterpret_cast<const f16x8*>(hi + brow[j] + toff);
-            if (LO_INPUT) bl[b][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff);
+            for (int f = 0; f < SMF; f++) {
+                ah[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 0) * 64 + lane];
+                al[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < SNF; j++) {
+                bh[b][kh][j] = *reinterpret_cast<const f16x8*>(hi + brow[j] + toff + 16 * kh);
+                if (LO_INPUT) bl[b][kh][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff + 16 * kh);
+            }
         }
     };
-    auto mfmas = [&](int b) {  // product by product: 24 independent accumulators between two uses of the same one
+    auto mfmas = [&](int b) {  // product by product: 6 independent accumulators between two uses of the same one
 #pragma unroll
-        for (int f = 0; f < SMF; f++)
-#pragma unroll
-            for (int j = 0; j < SNF; j++) SMFMA(ah[b][f], bh[b][j], acc[f][j]);
-        if (LO_INPUT) {
+        for (int kh = 0; kh < 2; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++)
 #pragma unroll
-                for (int j = 0; j < SNF; j++) SMFMA(ah[b][f], bl[b][j], acc[f][j]);
+                for (int j = 0; j < SNF; j++) SMFMA(ah[b][kh][f], bh[b][kh][j], acc[f][j]);
+            if (LO_INPUT) {
+#pragma unroll
+                for (int f = 0; f < SMF; f++)
+#pragma unroll
+                    for (int j = 0; j < SNF; j++) SMFMA(ah[b][kh][f], bl[b][kh][j], acc[f][j]);
+            }
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int j = 0; j < SNF; j++) SMFMA(al[b][kh][f], bh[b][kh][j], acc[f][j]);
         }
-#pragma unroll
-        for (int f = 0; f < SMF; f++)
-#pragma unroll
-            for (int j = 0; j < SNF; j++) SMFMA(al[b][f], bh[b][j], acc[f][j]);
     };
     fetch(0, 0);
     for (int sl = 0; sl < NSL; sl += 2) {
@@ -100,23 +111,27 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     }
 }
 
-// v = SiLU(acc * inv + bias) for every (fragment, cell) of this lane -> split -> image, in place
+// this lane's values -> split -> image, in place.  32x32 accumulator: register 4 q + r of fragment f is channel
+// ch0 + 32 f + 8 q + r (ch0 = 64 wa + 4 (lane / 32)) of cell column lane % 32
 __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int ch0,
-                                   const f32x4 (&val)[SMF][SNF]) {
+                                   const f32x16 (&val)[SMF][SNF]) {
 #pragma unroll
     for (int f = 0; f < SMF; f++)
 #pragma unroll
         for (int j = 0; j < SNF; j++)
             if (live[j]) {
-                f16x4 oh, ol;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    oh[r] = (_Float16)val[f][j][r];
-                    ol[r] = (_Float16)(val[f][j][r] - (float)oh[r]);
+                for (int q = 0; q < 4; q++) {
+                    f16x4 oh, ol;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        oh[r] = (_Float16)val[f][j][4 * q + r];
+                        ol[r] = (_Float16)(val[f][j][4 * q + r] - (float)oh[r]);
+                    }
+                    const int at = crow[j] + ch0 + 32 * f + 8 * q;
+                    *reinterpret_cast<f16x4*>(hi + at) = oh;
+                    *reinterpret_cast<f16x4*>(lo + at) = ol;
                 }
-                const int at = crow[j] + ch0 + 16 * f;
-                *reinterpret_cast<f16x4*>(hi + at) = oh;
-                *reinterpret_cast<f16x4*>(lo + at) = ol;
             }
 }
 
@@ -155,40 +170,44 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         }
     }
     __syncthreads();
-    // wave (wa, wb): channels 64 wa .. 64 wa + 63 (fragments 4 wa .. 4 wa + 3) x cells 96 wb .. 96 wb + 95
-    const int wa = wave & 1, wb = wave >> 1, fbase = 4 * wa, ch0 = 64 * wa + 4 * g;
+    // wave (wa, wb): channels 64 wa .. 64 wa + 63 (32-channel fragments 2 wa, 2 wa + 1) x cells 96 wb .. 96 wb + 95
+    const int wa = wave & 1, wb = wave >> 1, fbase = 2 * wa, l32 = lane & 31, kg = lane >> 5, ch0 = 64 * wa + 4 * kg;
     int brow[SNF], crow[SNF];
     bool live[SNF];
 #pragma unroll
     for (int j = 0; j < SNF; j++) {
-        int col = wb * 96 + j * 16 + n16;
+        int col = wb * 96 + j * 32 + l32;
         live[j] = col < SCELLS;
         if (!live[j]) col = 0;
         const int s = col / 42, p = col % 42;
         crow[j] = scell(s, p / 7, p % 7) * SRS;
-        brow[j] = crow[j] + 8 * g;
+        brow[j] = crow[j] + 8 * kg;
     }
-    f32x4 acc[SMF][SNF];
-    auto zero = [&](f32x4 (&a)[SMF][SNF]) {
+    f32x16 acc[SMF][SNF];
+    auto zero = [&](f32x16 (&a)[SMF][SNF]) {
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
-            for (int j = 0; j < SNF; j++) a[f][j] = (f32x4){0, 0, 0, 0};
-    };
-    // a = SiLU(a * inv + bias[channel]) (+ res)
-    auto activate = [&](f32x4 (&a)[SMF][SNF], const float* bias, float inv, const f32x4 (*res)[SNF]) {
-#pragma unroll
-        for (int f = 0; f < SMF; f++) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ch0 + 16 * f);
-#pragma unroll
             for (int j = 0; j < SNF; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = a[f][j][r] * inv + bb[r];
-                    if (res) v += res[f][j][r];
-                    a[f][j][r] = ssilu(v);
-                }
-        }
+                for (int i = 0; i < 16; i++) a[f][j][i] = 0.f;
+    };
+    // a = SiLU(a * inv + bias[channel] (+ res))
+    auto activate = [&](f32x16 (&a)[SMF][SNF], const float* bias, float inv, const f32x16 (*res)[SNF]) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ch0 + 32 * f + 8 * q);
+#pragma unroll
+                for (int j = 0; j < SNF; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float v = a[f][j][4 * q + r] * inv + bb[r];
+                        if (res) v += res[f][j][4 * q + r];
+                        a[f][j][4 * q + r] = ssilu(v);
+                    }
+            }
     };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     zero(acc);
@@ -200,16 +219,18 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
 
     // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
     for (int blk = 0; blk < 3; blk++) {
-        f32x4 xres[SMF][SNF];  // this lane's own entries of x, kept for the residual while the image holds t
+        f32x16 xres[SMF][SNF];  // this lane's own entries of x, kept for the residual while the image holds t
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
-            for (int j = 0; j < SNF; j++) {
-                const int at = crow[j] + ch0 + 16 * f;
-                const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
+            for (int j = 0; j < SNF; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) xres[f][j][r] = (float)xh[r] + (float)xl[r];
-            }
+                for (int q = 0; q < 4; q++) {
+                    const int at = crow[j] + ch0 + 32 * f + 8 * q;
+                    const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) xres[f][j][4 * q + r] = (float)xh[r] + (float)xl[r];
+                }
         zero(acc);
         conv_split<9, 4, true>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
@@ -224,32 +245,30 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         __syncthreads();
     }
 
-    // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment; the waves
-    // with wa == 0 do it for their cells
+    // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment of
+    // v_mfma_f32_16x16x32_f16 (cell = lane % 16, k group = lane / 16); the waves with wa == 0 do it for their 96 cells
     if (wa == 0) {
-        f32x4 ah_[SNF];
 #pragma unroll
-        for (int j = 0; j < SNF; j++) ah_[j] = (f32x4){0, 0, 0, 0};
+        for (int jj = 0; jj < 6; jj++) {
+            int col = wb * 96 + jj * 16 + n16;
+            const bool lv = col < SCELLS;
+            if (!lv) col = 0;
+            const int sp = col / 42, p = col % 42;
+            const int b16 = scell(sp, p / 7, p % 7) * SRS + 8 * g;
+            f32x4 a4 = (f32x4){0, 0, 0, 0};
 #pragma unroll
-        for (int cs = 0; cs < 4; cs++) {
-            const f16x8 wh = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane], wl = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < SNF; j++) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(hi + brow[j] + cs * 32);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(lo + brow[j] + cs * 32);
-                SMFMA(wh, bh, ah_[j]);
-                SMFMA(wh, bl, ah_[j]);
-                SMFMA(wl, bh, ah_[j]);
+            for (int cs = 0; cs < 4; cs++) {
+                const f16x8 wh = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane], wl = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(hi + b16 + cs * 32);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(lo + b16 + cs * 32);
+                SMFMA16(wh, bh, a4);
+                SMFMA16(wh, bl, a4);
+                SMFMA16(wl, bh, a4);
             }
-        }
-        if (g == 0) {
+            if (g == 0 && lv) {
 #pragma unroll
-            for (int j = 0; j < SNF; j++)
-                if (live[j]) {
-                    const int col = wb * 96 + j * 16 + n16;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) hb[r][col] = ssilu(ah_[j][r] * w.inv_head + w.b_head[r]);
-                }
+                for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * w.inv_head + w.b_head[r]);
+            }
         }
     }
     __syncthreads();
@@ -358,8 +377,8 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     };
     const float* wt = br.take(128 * 3 * 9);
     CnnBn bn = cnn_take_bn(br, 128);
-    c->d.inv_stem = pack_split(9 * SMFT, [&](int fr, int l, int i) {
-        const int tap = fr / SMFT, f = fr % SMFT, co = 16 * f + l % 16, ci = 8 * (l / 16) + i;
+    c->d.inv_stem = pack_split(9 * 2 * SMFT, [&](int fr, int l, int i) {
+        const int tap = fr / (2 * SMFT), kh = (fr / SMFT) % 2, f = fr % SMFT, co = 32 * f + l % 32, ci = 16 * kh + 8 * (l / 32) + i;
         return ci < 3 ? (double)wt[((size_t)co * 3 + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co) : 0.0;
     }, pk);
     up16(&c->d.w_stem);
@@ -367,16 +386,18 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     for (int b = 0; b < 3; b++) {
         wt = br.take((size_t)128 * 128 * 9);
         bn = cnn_take_bn(br, 128);
-        c->d.inv3[b] = pack_split(36 * SMFT, [&](int fr, int l, int i) {
-            const int sl = fr / SMFT, f = fr % SMFT, tap = sl >> 2, cs = sl & 3, co = 16 * f + l % 16, ci = 32 * cs + 8 * (l / 16) + i;
+        c->d.inv3[b] = pack_split(36 * 2 * SMFT, [&](int fr, int l, int i) {
+            const int sl = fr / (2 * SMFT), kh = (fr / SMFT) % 2, f = fr % SMFT, tap = sl >> 2, cs = sl & 3, co = 32 * f + l % 32,
+                      ci = 32 * cs + 16 * kh + 8 * (l / 32) + i;
             return (double)wt[((size_t)co * SCH + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w3[b]);
         if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b3[b]);
         wt = br.take((size_t)128 * 128);
         bn = cnn_take_bn(br, 128);
-        c->d.inv1[b] = pack_split(4 * SMFT, [&](int fr, int l, int i) {
-            const int cc = fr / SMFT, f = fr % SMFT, co = 16 * f + l % 16, ci = 32 * cc + 8 * (l / 16) + i;
+        c->d.inv1[b] = pack_split(4 * 2 * SMFT, [&](int fr, int l, int i) {
+            const int cc = fr / (2 * SMFT), kh = (fr / SMFT) % 2, f = fr % SMFT, co = 32 * f + l % 32,
+                      ci = 32 * cc + 16 * kh + 8 * (l / 32) + i;
             return (double)wt[(size_t)co * SCH + ci] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w1[b]);
