@@ -15,6 +15,7 @@ GAME_C4, GAME_TTT, GAME_NBTTT = 0, 1, 2
 EVAL_UNIFORM, EVAL_HASH, EVAL_CNN, EVAL_HOST, EVAL_ROLLOUT, EVAL_ROLLOUT_HASH = 0, 1, 2, 3, 4, 5
 FLIP_NEVER, FLIP_STREAM, FLIP_RANDOM = 0, 1, 2
 MOVE_FIRST_MAX, MOVE_SAMPLE = 0, 1
+K3_KINDS = {None: 0, "default": 0, "wino": 1, "split": 2, "direct": 3}
 GAME_IDS = {"Connect4": GAME_C4, "TTT": GAME_TTT, "NBTTT": GAME_NBTTT}
 
 
@@ -29,6 +30,7 @@ class az_config(C.Structure):
         ("flip_mode", C.c_int32), ("reuse_tree", C.c_int32), ("dirichlet_alpha", C.c_double),
         ("rng_seed", C.c_uint64), ("move_mode", C.c_int32), ("max_plies", C.c_int32),
         ("nodes_per_game", C.c_int64), ("game_id_base", C.c_uint64), ("n_cohorts", C.c_int32),
+        ("game_id_stride", C.c_uint64),
     ]
 
 
@@ -74,6 +76,7 @@ SIGNATURES = {
     "az_choose_moves": (C.c_int, [_vp, _vp, _dbl, _vp, _vp]),
     "az_advance": (C.c_int, [_vp, _vp]),
     "az_set_game_target": (C.c_int, [_vp, _i64]),
+    "az_set_active": (C.c_int, [_vp, _vp]),
     "az_selfplay": (_i64, [_vp, _i64, _dbl, _i32, _i64]),
     "az_selfplay_step": (C.c_int, [_vp, _dbl, _i32, _i32]),
     "az_selfplay_rounds": (C.c_int, [_vp, _i32, _dbl, _i32, _i32]),
@@ -85,7 +88,10 @@ SIGNATURES = {
     "az_traj_unpack_dev": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "az_net_load": (C.c_int, [_vp, _vp, C.c_size_t]),
     "az_net_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "az_net_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "az_net_get_kernel": (C.c_int, [_vp]),
     "az_net_forward_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "az_set_root_children": (C.c_int, [_vp, _vp, _vp, _vp]),
     "az_puct_batch": (C.c_int, [C.c_int, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 

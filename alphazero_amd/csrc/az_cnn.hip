@@ -451,23 +451,46 @@ static void pack_conv1(const float* wt, const CnnBn& bn, std::vector<float4>& ou
             }
 }
 
-int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out) {
+// which kernel evaluates: the caller's choice (az_net_set_kernel), else the environment (diagnostic runs of the whole test
+// suite on one kernel: AZ_K3=wino|split|direct; AZ_K3_SPLIT=1 / AZ_K3_DIRECT=1 are the older spellings), else the default
+static int resolve_k3(int kind) {
+    if (kind != AZ_K3_DEFAULT) return kind;
+    const char* k = getenv("AZ_K3");
+    if (k && !strcmp(k, "wino")) return AZ_K3_WINO;
+    if (k && !strcmp(k, "split")) return AZ_K3_SPLIT;
+    if (k && !strcmp(k, "direct")) return AZ_K3_DIRECT;
+    const char* split = getenv("AZ_K3_SPLIT");
+    if (split && split[0] == '1') return AZ_K3_SPLIT;
+    const char* direct = getenv("AZ_K3_DIRECT");
+    if (direct && direct[0] == '1') return AZ_K3_DIRECT;
+    return AZ_K3_PRODUCT;
+}
+
+int cnn_kind(const Cnn* c) { return c->split ? AZ_K3_SPLIT : (c->wino ? AZ_K3_WINO : AZ_K3_DIRECT); }
+
+int cnn_create(const float* blob, size_t n_floats, int kind, Cnn** out) {
     if (!blob || n_floats != 500106) {
         set_error("az_net_load: expected 500106 float32 values (the reference CNN state_dict, see include/azamd.h)");
         return AZ_ERR_ARG;
     }
+    for (size_t i = 0; i < n_floats; i++)
+        if (!isfinite(blob[i])) {   // q14: the reference would play on with whatever it has; this engine refuses
+            set_error("az_net_load: the weight blob holds a non-finite value at index " + std::to_string(i));
+            return AZ_ERR_ARG;
+        }
+    kind = resolve_k3(kind);
     Cnn* c = new Cnn();
     memset(&c->d, 0, sizeof(c->d));
-    const char* split = getenv("AZ_K3_SPLIT");  // opt-in experimental kernel (az_cnn_split.hip)
-    if (split && split[0] == '1') {
+    if (kind == AZ_K3_SPLIT) {
         int rcs = cnns_create(blob, n_floats, &c->split);
         if (rcs != AZ_OK) {
             delete c;
             return rcs;
         }
+        *out = c;
+        return AZ_OK;
     }
-    const char* direct = getenv("AZ_K3_DIRECT");  // diagnostic A/B switch; the product kernel is the Winograd form
-    if (!(direct && direct[0] == '1')) {
+    if (kind == AZ_K3_WINO) {
         int rcw = cnnw_create(blob, n_floats, &c->wino);
         if (rcw != AZ_OK) {
             delete c;
@@ -475,6 +498,11 @@ int cnn_create(const float* blob, size_t n_floats, int /*max_batch*/, Cnn** out)
         }
         *out = c;
         return AZ_OK;
+    }
+    if (kind != AZ_K3_DIRECT) {
+        delete c;
+        set_error("az_net_set_kernel: unknown kernel kind");
+        return AZ_ERR_ARG;
     }
     CnnBlobReader br{blob};
     int rc = AZ_OK;

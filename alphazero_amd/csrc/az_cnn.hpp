@@ -13,7 +13,10 @@ struct Cnn;   // device-resident folded weights of the selected kernel
 struct CnnW;  // Winograd-form weights
 struct CnnS;  // split-fp16 form (experimental, AZ_K3_SPLIT=1)
 
-int cnn_create(const float* blob, size_t n_floats, int max_batch, Cnn** out);
+// kind: AZ_K3_* of include/azamd.h (AZ_K3_DEFAULT: environment override, else the product kernel AZ_K3_PRODUCT)
+constexpr int AZ_K3_PRODUCT = AZ_K3_WINO;
+int cnn_create(const float* blob, size_t n_floats, int kind, Cnn** out);
+int cnn_kind(const Cnn* c);
 void cnn_destroy(Cnn* c);
 // n packed Connect4 positions (device) -> optional logp[n][7], logv[n][3], probs[n][7], value[n] (device).
 int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, float* probs, float* value,

@@ -1,15 +1,24 @@
-// az_cnn_split.hip -- K3, experimental form (opt-in: AZ_K3_SPLIT=1; the product kernel stays az_cnn_wino.hip).
+// az_cnn_split.hip -- K3 on the fp16 MFMA pipe with fp32-accurate products (AZ_K3_SPLIT; az_net_set_kernel).
 //
 // The same network (Connect4/Network.py:19-27,31-51,60-64,78-85; BatchNorm folded) as a DIRECT implicit GEMM on
-// fp16 MFMA (v_mfma_f32_32x32x16_f16 in the tile loops), with every fp32 product a*w computed as hi*hi + hi*lo + lo*hi, hi/lo = the fp16 halves of the
-// fp32 operands (22 mantissa bits; the dropped lo*lo term is 2^-22 relative), accumulated in fp32.  Weights are folded
-// in float64, scaled by a power of two per layer (their lo halves stay clear of the fp16 subnormals) and split on the
-// host; the activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
+// fp16 MFMA (v_mfma_f32_32x32x16_f16 in the tile loops), with every fp32 product a*w computed as hi*hi + hi*lo + lo*hi,
+// hi/lo = the fp16 halves of the fp32 operands (22 mantissa bits; the dropped lo*lo term is 2^-22 relative), accumulated
+// in fp32.
+// RANGE (why no half can leave fp16's exponent range, whatever the weights and the position):
+//   weights     folded in float64, scaled per layer by a power of two so that the largest is in [2^13, 2^14), split on the
+//               host: hi <= 2^14 < 65504; a weight's lo half is exact down to 2^-24, i.e. 2^-38 of the layer's largest weight;
+//   activations rescaled PER POSITION AND LAYER by a power of two 2^e, e chosen in the kernel from the largest magnitude
+//               of that position's 42 x 128 values (one LDS ds_max_u32 per lane and column) so that it lands in
+//               [2^13, 2^14); the consumer multiplies its fp32 accumulators by 2^-e (exact).  hi never overflows, and an
+//               element's lo half is exact down to 2^-24 * 2^-e, i.e. 2^-37 of the position's largest activation -- far
+//               below the 2^-24 relative rounding of the fp32 accumulation that every fp32 kernel has as well.
+//   A position's scale depends on that position only, so its result does not depend on its neighbours in the batch.
+// The activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
 // image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup; its 4 waves are a
 // 2 x 2 grid, a wave owns 64 output channels x 96 cells.  Inside a residual block a lane keeps its own entries of x in
 // registers for the residual, t = SiLU(BN(conv3x3(x))) goes through the image and the 1x1 convolution is the same
 // routine with one tap.  Prototypes and measurements: tools/ubench/{conv,block}_split_f16.hip, tools/k3_accuracy.py,
-// tools/split_fp16_accuracy.py; DESIGN.md section 8.
+// tools/split_fp16_accuracy.py; DESIGN.md section 4.
 #include <string.h>
 
 #include <vector>
@@ -111,10 +120,19 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     }
 }
 
-// this lane's values -> split -> image, in place.  32x32 accumulator: register 4 q + r of fragment f is channel
-// ch0 + 32 f + 8 q + r (ch0 = 64 wa + 4 (lane / 32)) of cell column lane % 32
+// power-of-two scale that brings a position's largest magnitude m into [2^13, 2^14), and its inverse (both exact).
+// m's biased exponent E is clamped to [20, 240] (m outside 2^-107 .. 2^113 is no network any more; m == 0: all zero).
+__device__ inline void range_scale(float m, float& sc, float& isc) {
+    int E = (int)((__float_as_uint(m) >> 23) & 0xFFu);
+    E = E < 20 ? 20 : (E > 240 ? 240 : E);
+    sc = __uint_as_float((u32)(267 - E) << 23);    // 2^(13 - (E - 127))
+    isc = __uint_as_float((u32)(E - 13) << 23);    // 2^((E - 127) - 13)
+}
+
+// this lane's values, times the position's scale -> split -> image, in place.  32x32 accumulator: register 4 q + r of
+// fragment f is channel ch0 + 32 f + 8 q + r (ch0 = 64 wa + 4 (lane / 32)) of cell column lane % 32
 __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int ch0,
-                                   const f32x16 (&val)[SMF][SNF]) {
+                                   const f32x16 (&val)[SMF][SNF], const float (&sc)[SNF]) {
 #pragma unroll
     for (int f = 0; f < SMF; f++)
 #pragma unroll
@@ -125,8 +143,9 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
                     f16x4 oh, ol;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        oh[r] = (_Float16)val[f][j][4 * q + r];
-                        ol[r] = (_Float16)(val[f][j][4 * q + r] - (float)oh[r]);
+                        const float v = val[f][j][4 * q + r] * sc[j];
+                        oh[r] = (_Float16)v;
+                        ol[r] = (_Float16)(v - (float)oh[r]);
                     }
                     const int at = crow[j] + ch0 + 32 * f + 8 * q;
                     *reinterpret_cast<f16x4*>(hi + at) = oh;
@@ -143,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
     __shared__ float hb[4][SCELLS];  // head activations: 3 policy channels, 1 value channel
     __shared__ float s_player[SNS];
     __shared__ long long s_slot[SNS];
+    __shared__ u32 s_amax[7][SNS];   // per layer output and position: bits of the largest |activation| (ds_max_u32)
     _Float16* hi = lds;
     _Float16* lo = lds + SROWS * SRS;
     const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
     if (s0 >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
     for (int i = tid; i < SROWS * SRS; i += 256) reinterpret_cast<unsigned*>(lds)[i] = 0u;
+    if (tid < 7 * SNS) (&s_amax[0][0])[tid] = 0u;
     __syncthreads();
     // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149): channels 0..2, exact in fp16
     if (tid < SCELLS) {
@@ -172,16 +193,20 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
     __syncthreads();
     // wave (wa, wb): channels 64 wa .. 64 wa + 63 (32-channel fragments 2 wa, 2 wa + 1) x cells 96 wb .. 96 wb + 95
     const int wa = wave & 1, wb = wave >> 1, fbase = 2 * wa, l32 = lane & 31, kg = lane >> 5, ch0 = 64 * wa + 4 * kg;
-    int brow[SNF], crow[SNF];
+    int brow[SNF], crow[SNF], cpos[SNF];
     bool live[SNF];
+    float sc[SNF], isc[SNF];   // scale of the image's current contents for this lane's columns (its position's), and 1/scale
 #pragma unroll
     for (int j = 0; j < SNF; j++) {
         int col = wb * 96 + j * 32 + l32;
         live[j] = col < SCELLS;
         if (!live[j]) col = 0;
         const int s = col / 42, p = col % 42;
+        cpos[j] = s;
         crow[j] = scell(s, p / 7, p % 7) * SRS;
         brow[j] = crow[j] + 8 * kg;
+        sc[j] = 1.f;    // the input planes are 0 / +-1
+        isc[j] = 1.f;
     }
     f32x16 acc[SMF][SNF];
     auto zero = [&](f32x16 (&a)[SMF][SNF]) {
@@ -192,8 +217,11 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
 #pragma unroll
                 for (int i = 0; i < 16; i++) a[f][j][i] = 0.f;
     };
-    // a = SiLU(a * inv + bias[channel] (+ res))
+    // a = SiLU(a * (inv / scale of the image the convolution read) + bias[channel] (+ res))
     auto activate = [&](f32x16 (&a)[SMF][SNF], const float* bias, float inv, const f32x16 (*res)[SNF]) {
+        float invj[SNF];
+#pragma unroll
+        for (int j = 0; j < SNF; j++) invj[j] = inv * isc[j];
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
@@ -203,19 +231,35 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
                 for (int j = 0; j < SNF; j++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        float v = a[f][j][4 * q + r] * inv + bb[r];
+                        float v = a[f][j][4 * q + r] * invj[j] + bb[r];
                         if (res) v += res[f][j][4 * q + r];
                         a[f][j][4 * q + r] = ssilu(v);
                     }
             }
     };
+    // the layer's output a -> image: every position's largest magnitude through LDS, scale, split, store.  The first
+    // barrier is also the one after which no wave reads the image's old contents any more.
+    auto to_image = [&](int layer, const f32x16 (&a)[SMF][SNF]) {
+#pragma unroll
+        for (int j = 0; j < SNF; j++) {
+            float m = 0.f;
+#pragma unroll
+            for (int f = 0; f < SMF; f++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) m = fmaxf(m, fabsf(a[f][j][i]));
+            if (live[j]) atomicMax(&s_amax[layer][cpos[j]], __float_as_uint(m));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SNF; j++) range_scale(__uint_as_float(s_amax[layer][cpos[j]]), sc[j], isc[j]);
+        store_image(hi, lo, crow, live, ch0, a, sc);
+        __syncthreads();
+    };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     zero(acc);
     conv_split<9, 1, false>(w.w_stem, hi, lo, brow, lane, fbase, acc);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
-    __syncthreads();  // every wave has read the input planes
-    store_image(hi, lo, crow, live, ch0, acc);
-    __syncthreads();
+    to_image(0, acc);
 
     // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
     for (int blk = 0; blk < 3; blk++) {
@@ -229,20 +273,16 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
                     const int at = crow[j] + ch0 + 32 * f + 8 * q;
                     const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) xres[f][j][4 * q + r] = (float)xh[r] + (float)xl[r];
+                    for (int r = 0; r < 4; r++) xres[f][j][4 * q + r] = ((float)xh[r] + (float)xl[r]) * isc[j];
                 }
         zero(acc);
         conv_split<9, 4, true>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
-        __syncthreads();  // every wave is done with x as a convolution input
-        store_image(hi, lo, crow, live, ch0, acc);  // t
-        __syncthreads();
+        to_image(1 + 2 * blk, acc);  // t
         zero(acc);
         conv_split<1, 4, true>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
         activate(acc, w.b1[blk], w.inv1[blk], xres);
-        __syncthreads();  // every wave is done with t
-        store_image(hi, lo, crow, live, ch0, acc);
-        __syncthreads();
+        to_image(2 + 2 * blk, acc);
     }
 
     // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment of
@@ -266,8 +306,10 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
                 SMFMA16(wl, bh, a4);
             }
             if (g == 0 && lv) {
+                float hsc, hisc;   // the image holds the last block's output at its position's scale
+                range_scale(__uint_as_float(s_amax[6][sp]), hsc, hisc);
 #pragma unroll
-                for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * w.inv_head + w.b_head[r]);
+                for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * (w.inv_head * hisc) + w.b_head[r]);
             }
         }
     }

@@ -100,6 +100,7 @@ struct az_engine {
     float *rc_q = nullptr, *rc_p = nullptr, *rc_rootQ = nullptr;
     u8* d_flags8 = nullptr;
     Cnn* net = nullptr;
+    int k3_kind = AZ_K3_DEFAULT;   // az_net_set_kernel
     unsigned long long target = 0;
     int recording = 0;
     // rolling self-play (az_selfplay_rounds): leaves are parked between calls; parity of the leaf counter in use
@@ -409,6 +410,8 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     d.eval_seed = cfg->eval_seed;
     d.flip_mode = gi.LG && cfg->game != AZ_GAME_NBTTT ? cfg->flip_mode : AZ_FLIP_NEVER;
     d.rng_seed = cfg->rng_seed;
+    d.gid_stride = cfg->game_id_stride ? cfg->game_id_stride : 1ull;
+    e->cfg.game_id_stride = d.gid_stride;
     d.noise_alpha = cfg->dirichlet_alpha > 0 ? (float)cfg->dirichlet_alpha : 0.f;
     int rc = AZ_OK;
 #define A_(ptr, n) if (rc == AZ_OK) rc = e->dalloc(&(ptr), (size_t)(n))
@@ -869,6 +872,40 @@ int az_get_root_children(az_engine* e, int32_t* actions, int32_t* visits, float*
     return AZ_OK;
 }
 
+// test hook: every slot's tree becomes a root with the given children (insertion order), so that move selection can be
+// checked on recorded (actions, visits) pairs without a search that happens to produce them
+int az_set_root_children(az_engine* e, const int32_t* actions, const int32_t* visits, const int32_t* n_children) {
+    AZ_CHECK_E(e);
+    if (!actions || !visits || !n_children) return bad_arg("az_set_root_children");
+    const Dev& d = e->d;
+    if (d.cap < 1 + d.A) {
+        set_error("az_set_root_children: the node arena is smaller than a root and its children");
+        return AZ_ERR_STATE;
+    }
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    std::vector<uint4> rec((size_t)(1 + d.A));
+    std::vector<u32> one(d.G, 0u), na(d.G, (u32)(1 + d.A));
+    for (int g = 0; g < d.G; g++) {
+        const int k = n_children[g];
+        if (k < 0 || k > d.A) return bad_arg("az_set_root_children");
+        long long tot = 1;
+        for (int i = 0; i < d.A; i++) {
+            const int a = i < k ? actions[(size_t)g * d.A + i] : 0, v = i < k ? visits[(size_t)g * d.A + i] : 0;
+            if (i < k && (a < 0 || a >= d.A || v < 0)) return bad_arg("az_set_root_children");
+            rec[1 + i] = make_uint4((u32)v, 0u, 0u, (u32)a << 28);
+            tot += v;
+        }
+        float pone = 1.0f;
+        u32 pbits;
+        memcpy(&pbits, &pone, 4);
+        rec[0] = make_uint4((u32)tot, 0u, pbits, 1u | ((u32)k << 24));
+        AZ_HIP(hipMemcpy(d.nodes + (i64)g * d.cap, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    AZ_HIP(hipMemcpy(d.root, one.data(), d.G * sizeof(u32), hipMemcpyHostToDevice));
+    AZ_HIP(hipMemcpy(d.n_alloc, na.data(), d.G * sizeof(u32), hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
 int az_choose_moves(az_engine* e, const double* temps, double temp_all, int32_t* actions, float* pi) {
     AZ_CHECK_E(e);
     const Dev& d = e->d;
@@ -1009,6 +1046,18 @@ int az_set_game_target(az_engine* e, int64_t n_games_target) {
     return AZ_OK;
 }
 
+int az_set_active(az_engine* e, const uint8_t* mask) {
+    AZ_CHECK_E(e);
+    if (!mask) return bad_arg("az_set_active");
+    const Dev& d = e->d;
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    std::vector<u8> done(d.G), act(d.G);
+    AZ_HIP(hipMemcpy(done.data(), d.done, d.G, hipMemcpyDeviceToHost));
+    for (int g = 0; g < d.G; g++) act[g] = (mask[g] && !done[g]) ? 1 : 0;   // a finished game is never searched again
+    AZ_HIP(hipMemcpy(d.active, act.data(), d.G, hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
 int64_t az_selfplay(az_engine* e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_steps) {
     AZ_CHECK_E(e);
     if (n_games_target <= 0) return bad_arg("az_selfplay");
@@ -1118,7 +1167,23 @@ int az_net_load(az_engine* e, const float* blob, size_t n_floats) {
         cnn_destroy(e->net);
         e->net = nullptr;
     }
-    return cnn_create(blob, n_floats, e->d.G, &e->net);
+    return cnn_create(blob, n_floats, e->k3_kind, &e->net);
+}
+
+int az_net_set_kernel(az_engine* e, int kind) {
+    AZ_CHECK_E(e);
+    if (kind < AZ_K3_DEFAULT || kind > AZ_K3_DIRECT) return bad_arg("az_net_set_kernel");
+    e->k3_kind = kind;
+    return AZ_OK;
+}
+
+int az_net_get_kernel(az_engine* e) {
+    AZ_CHECK_E(e);
+    if (!e->net) {
+        set_error("az_net_get_kernel: call az_net_load first");
+        return AZ_ERR_NO_NET;
+    }
+    return cnn_kind(e->net);
 }
 
 int az_net_forward(az_engine* e, int64_t n, const uint64_t* states, float* logp, float* logv, float* probs,

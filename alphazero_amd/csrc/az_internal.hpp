@@ -53,6 +53,7 @@ struct Dev {
     u64* sim_ctr;         // [G] playouts ever run in this slot's current game (RNG counter)
     i32* move_sims;       // [G] rolling self-play: playouts done for the move being searched
     u64* game_id;         // [G]
+    u64 gid_stride;       // global game id of the k-th game this engine starts = game_id_base + gid_stride * k
     u64 rng_seed;
     float noise_alpha;    // <=0: off
     // split-phase buffers (select -> evaluate -> backup)

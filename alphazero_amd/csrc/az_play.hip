@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_init_slots(Dev d, int use_openings, u64
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
     typename G::State s;
-    u64 gid = gid_base + (u64)g;
+    u64 gid = gid_base + d.gid_stride * (u64)g;
     if (use_openings) {
         s = opening_state<G>(d, gid);
         for (int i = 0; i < G::W; i++) d.root_state[(i64)g * G::W + i] = s.w[i];

@@ -193,8 +193,19 @@ __device__ inline void advance_game(const Dev& d, const Play& p, int g, int a, c
         atomicAdd(&d.stats[ST_GAMES], 1ull);
         if (record) {  // game.py:50-58: commit the finished game with z from each mover's perspective
             int n = ply < G::MAX_PLIES ? ply : G::MAX_PLIES;
-            unsigned long long off = atomicAdd(p.out_count, (unsigned long long)n);
-            if ((i64)off + n <= p.out_cap) {
+            // reserve n rows with a compare-and-swap loop: out_count only ever covers rows that get written, so a game
+            // that does not fit is dropped without leaving a hole and later, shorter games may still fit
+            unsigned long long off = atomicAdd(p.out_count, 0ull);
+            bool fits = false;
+            while ((i64)off + n <= p.out_cap) {
+                const unsigned long long prev = atomicCAS(p.out_count, off, off + (unsigned long long)n);
+                if (prev == off) {
+                    fits = true;
+                    break;
+                }
+                off = prev;
+            }
+            if (fits) {
                 for (int j = 0; j < n; j++) {
                     i64 o = (i64)g * G::MAX_PLIES + j, q = (i64)off + j;
                     for (int i = 0; i < G::W; i++) p.out_state[q * G::W + i] = p.tj_state[o * G::W + i];
@@ -218,9 +229,16 @@ __device__ inline void advance_game(const Dev& d, const Play& p, int g, int a, c
 template <class G>
 __device__ inline void refill_game(const Dev& d, const Play& p, int g, unsigned long long target, u64 gid_base) {
     if (d.active[g] || !d.done[g]) return;
-    unsigned long long idx = atomicAdd(p.games_started, 1ull);
-    if (idx >= target) return;
-    u64 gid = gid_base + idx;
+    // take the next game index while it is below the target (compare-and-swap: the counter never runs past the target,
+    // so the target may be raised between launches and exactly `target` games are ever started)
+    unsigned long long idx = atomicAdd(p.games_started, 0ull);
+    for (;;) {
+        if (idx >= target) return;
+        const unsigned long long prev = atomicCAS(p.games_started, idx, idx + 1ull);
+        if (prev == idx) break;
+        idx = prev;
+    }
+    u64 gid = gid_base + d.gid_stride * idx;
     typename G::State s = opening_state<G>(d, gid);
     for (int i = 0; i < G::W; i++) d.root_state[(i64)g * G::W + i] = s.w[i];
     d.nodes[(i64)g * d.cap] = make_uint4(0u, 0u, __float_as_uint(1.0f), 0u);

@@ -49,10 +49,11 @@ struct C4 {
     AZ_HD static u64 os(const State& s) { return s.w[1] & ~TURN_FLAG; }
     // env_cython.pyx:129-137: lowest empty cell of the column; full column -> false, nothing changes.
     AZ_HD static bool place(State& s, int col) {
+        if (col < 0 || col > 6) return false;  // before the shifts: an out-of-range column is no move at all
         u64 occ = xs(s) | os(s);
         u64 colmask = 0x3Full << (7 * col);
         u64 mv = (occ + (1ull << (7 * col))) & colmask;
-        if (col < 0 || col > 6 || mv == 0) return false;
+        if (mv == 0) return false;
         if (s.w[1] & TURN_FLAG) s.w[1] |= mv; else s.w[0] |= mv;
         return true;
     }
@@ -180,8 +181,9 @@ struct NBTTT {
     AZ_HD static u32 sub(const State& s, int b) { return (u32)((s.w[b / 3] >> (18 * (b % 3))) & 0x3FFFF); }
     AZ_HD static bool place(State& s, int a) {  // NBTTT/env.py:39-47
         int b = curr(s);
+        if (a < 0 || a > 8 || b > 8) return false;  // before sub(): a current-board nibble of 9..15 indexes no word
         u32 sb = sub(s, b);
-        if (a < 0 || a > 8 || b > 8 || (((sb | (sb >> 9)) >> a) & 1)) return false;
+        if (((sb | (sb >> 9)) >> a) & 1) return false;
         int sh = 18 * (b % 3) + ((s.w[3] & TURN_FLAG) ? 9 : 0) + a;
         s.w[b / 3] |= 1ull << sh;
         s.w[3] = (s.w[3] & ~15ull) | (u64)a;
@@ -211,11 +213,14 @@ struct NBTTT {
     }
     // build-defined: terminal draw when the CURRENT sub-board is full
     // (NBTTT/dependency/Negamax.c:34, utils.c:88-97), not the reference env's all-81 test.
+    // a caller-supplied state whose current-board nibble is 9..15 names no sub-board: no legal move, not full
     AZ_HD static bool full(const State& s) {
+        if (curr(s) > 8) return false;
         u32 sb = sub(s, curr(s));
         return ((sb | (sb >> 9)) & 0x1FF) == 0x1FF;
     }
     AZ_HD static u32 legal(const State& s) {
+        if (curr(s) > 8) return 0u;
         u32 sb = sub(s, curr(s));
         return ~(sb | (sb >> 9)) & 0x1FF;
     }

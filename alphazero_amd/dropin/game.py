@@ -6,6 +6,11 @@ Pipeline.data_collector run unchanged).  start_self_play_batch plays many games 
 import numpy as np
 
 
+def _seed(rng_seed):
+    """device RNG seed of a batched self-play call: the caller's, else one draw from the global np.random state"""
+    return int(np.random.randint(1 << 31)) if rng_seed is None else int(rng_seed)
+
+
 class Game:
     def __init__(self, env):
         self.env = env
@@ -51,12 +56,14 @@ class Game:
                 dones[-1] = True
                 return winner, zip(states, mcts_probs, winner_z, winner_z, next_states, dones)
 
-    def collect_self_play(self, player, buffer, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
+    def collect_self_play(self, player, buffer, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=None):
         """Pipeline.data_collector (Pipeline.py:53-63) in one call: play n_games in lockstep on the device with player's
         search settings and write every ply into `buffer` (the drop-in ReplayBuffer, or the reference's, with its tensors on the GPU)
         with collector.store_many -- trajectories never visit the host.  Under torch.distributed every rank plays
         n_games and every rank's buffer receives the plies of ALL ranks (RCCL all-gather of packed records).
-        Returns the list of episode lengths of the games stored (data_collector's episode_len is their mean)."""
+        Returns the list of episode lengths of the games stored (data_collector's episode_len is their mean).
+        rng_seed=None draws the device RNG seed from np.random like every random choice of the reference
+        (Pipeline.py:53-63 never seeds), so successive calls play different games; pass a number to replay one."""
         import torch
         from alphazero_amd.collector import TrajectoryGatherer, store_many
         from alphazero_amd.engine import SelfPlayEngine
@@ -65,11 +72,13 @@ class Game:
             raise NotImplementedError("batched self-play needs the device evaluator (the drop-in CNN)")
         game = self.env.GAME
         dev_index = getattr(m.policy, "device_index", 0)
-        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        ddp = torch.distributed.is_available() and torch.distributed.is_initialized()
+        rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if ddp else (0, 1)
         G = int(n_slots or min(n_games, 2048))
         eng = SelfPlayEngine(game, n_games=G, n_playout=m.n_playout, c_puct=m.c_init, evaluator="cnn", flip="random",
                              reuse_tree=bool(player.is_selfplay), dirichlet_alpha=None if m.deterministic else m.alpha,
-                             rng_seed=rng_seed, move="sample", device=dev_index, game_id_base=rank << 40)
+                             rng_seed=_seed(rng_seed), move="sample", device=dev_index, game_id_base=rank,
+                             game_id_stride=world)
         try:
             eng.load_net(m.policy.export_flat())
             eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
@@ -84,7 +93,7 @@ class Game:
         ends = torch.nonzero(recs[:, done_col]).flatten().cpu().numpy()
         return [int(x) for x in np.diff(np.concatenate([[-1], ends]))]
 
-    def start_self_play_batch(self, player, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=0):
+    def start_self_play_batch(self, player, n_games, temp=1, first_n_steps=5, n_slots=None, rng_seed=None):
         """n_games self-play games at once on the device (rolling rounds, include/azamd.h) with player's search settings (c_puct, n_playout, alpha,
         train/eval mode) and network.  Returns a list of (winner, [6-tuples]) in completion order, each 6-tuple as
         game.py:58 builds it: (state (1,C,H,W) f32, pi (A,) f32, z, z, next_state, done)."""
@@ -97,7 +106,7 @@ class Game:
         G = int(n_slots or min(n_games, 2048))
         eng = SelfPlayEngine(game, n_games=G, n_playout=m.n_playout, c_puct=m.c_init, evaluator="cnn", flip="random",
                              reuse_tree=bool(player.is_selfplay), dirichlet_alpha=None if m.deterministic else m.alpha,
-                             rng_seed=rng_seed, move="sample", device=getattr(m.policy, "device_index", 0))
+                             rng_seed=_seed(rng_seed), move="sample", device=getattr(m.policy, "device_index", 0))
         try:
             eng.load_net(m.policy.export_flat())
             eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))

@@ -21,7 +21,7 @@ MOVES = {"first_max": MOVE_FIRST_MAX, "sample": MOVE_SAMPLE}
 class SelfPlayEngine:
     def __init__(self, game="Connect4", n_games=1, n_playout=500, c_puct=1.25, evaluator="uniform", eval_seed=0,
                  flip="never", reuse_tree=True, dirichlet_alpha=None, rng_seed=0, move="first_max", device=0,
-                 max_plies=0, nodes_per_game=0, game_id_base=0, n_cohorts=0):
+                 max_plies=0, nodes_per_game=0, game_id_base=0, n_cohorts=0, game_id_stride=1):
         _abi.require_gpu()
         self.game = GAME_IDS.get(game, game)
         self.L = lib()
@@ -38,6 +38,7 @@ class SelfPlayEngine:
         cfg.rng_seed, cfg.move_mode = int(rng_seed), MOVES.get(move, move)
         cfg.max_plies, cfg.nodes_per_game, cfg.game_id_base = int(max_plies), int(nodes_per_game), int(game_id_base)
         cfg.n_cohorts = int(n_cohorts)
+        cfg.game_id_stride = int(game_id_stride)
         self.cfg = cfg
         self.n_playout = int(n_playout)
         h = C.c_void_p()
@@ -110,6 +111,13 @@ class SelfPlayEngine:
                                           ptr(out["root_q"])))
         return out
 
+    def set_root_children(self, actions, visits, n_children):
+        """test hook (include/azamd.h: az_set_root_children)"""
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.G, self.A)
+        v = np.ascontiguousarray(visits, dtype=np.int32).reshape(self.G, self.A)
+        n = np.ascontiguousarray(n_children, dtype=np.int32).reshape(self.G)
+        check(self.L.az_set_root_children(self.h, ptr(a), ptr(v), ptr(n)))
+
     # ---- moves
     def choose_moves(self, temp=0.0, temps=None):
         a = np.zeros(self.G, dtype=np.int32)
@@ -143,6 +151,11 @@ class SelfPlayEngine:
     def set_game_target(self, n):
         check(self.L.az_set_game_target(self.h, int(n)))
 
+    def set_active(self, mask):
+        """park (0) / resume (1) slots between calls (include/azamd.h: az_set_active)"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.G)
+        check(self.L.az_set_active(self.h, ptr(m)))
+
     def traj_count(self):
         g, p = C.c_int64(0), C.c_int64(0)
         check(self.L.az_traj_count(self.h, C.byref(g), C.byref(p)))
@@ -170,10 +183,19 @@ class SelfPlayEngine:
         return int(n)
 
     # ---- network
-    def load_net(self, blob):
+    def load_net(self, blob, kernel=None):
+        """az_net_load; kernel: None (keep the engine's choice), "default", "wino", "split" or "direct" (az_net_set_kernel)"""
         b = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        if kernel is not None:
+            check(self.L.az_net_set_kernel(self.h, _abi.K3_KINDS[kernel]))
         check(self.L.az_net_load(self.h, ptr(b), b.size))
         self._keep = b
+
+    @property
+    def k3_kernel(self):
+        k = self.L.az_net_get_kernel(self.h)
+        check(int(k))
+        return {1: "wino", 2: "split", 3: "direct"}[int(k)]
 
     def net_forward(self, states):
         s = _abi.as_u64(states).reshape(-1, 2)

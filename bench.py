@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the self-play hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on, per GPU): Connect4 self-play,
@@ -15,8 +15,11 @@ non-terminal leaf per live game; --mode lockstep runs one ply of every slot per 
 parity tests pin against the reference; both produce the same games (tests/test_gpu_cnn.py).  Finished trajectories
 are packed, all-gathered over RCCL (N>1) and expanded into ReplayBuffer-shaped tensors inside the timed region.
 
-value (games/s) = slot-plies per second / mean plies per finished game (steady-state estimator; the raw number of
-games that finished inside the timed window is reported as config.games_finished_in_window).
+value (games/s) = games that FINISH inside the timed window / wall time.  So that a window of a few game
+lengths means something, an untimed pre-roll de-synchronises the slots first: the first games start staggered over one
+mean game length (az_set_active) and play on until as many games have finished as there are slots, so the window sees
+slots at every game age; `value_steady_state_estimate` = slot-plies per second / mean plies per finished game is
+reported beside it (the two agree in steady state).
 """
 import argparse
 import json
@@ -49,6 +52,10 @@ EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi)
+# HBM bytes per launch of the split kernel (PMC pass, profiles/r01_k3_split.txt: 17.4 MB = its 3.8 MB of split weights per XCD L2)
+K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = 17.4e6
+K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC pass, profiles/r01_k3_split.txt"
+DEFAULT_K3 = "wino"              # the headline kernel
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -138,6 +145,89 @@ def _box_info(torch, local):
     return info
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes of this one, which has not
+    touched the GPU (nothing here imports torch or calls HIP), one rank per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    stdout is this process's stdout (the JSON line); the other ranks' goes to stderr.  Non-zero exit if any rank fails."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["AZ_BENCH_SELF_LAUNCHED"] = "1"
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0):    # one rank died: the others would wait in a collective for ever
+                    raise RuntimeError("rank %d exited with %d" % (procs.index(p), p.returncode))
+            time.sleep(0.2)
+        rc = max(abs(p.returncode) for p in procs)
+    except (RuntimeError, KeyboardInterrupt) as ex:
+        sys.stderr.write("bench.py launcher: %s; stopping the other ranks\n" % (ex,))
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+        rc = 1
+    return rc
+
+
+def run_stub(args, rank, world):
+    """--workload stub: the launcher / rendezvous / aggregation skeleton of the bench on CPU tensors over gloo, for the
+    CPU test of the N-rank launcher (tests/test_host.py).  No GPU, no engine; the line says so in `data`."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("AZ_BENCH_STUB_FAIL_RANK") == str(rank):   # the launcher test's failing rank
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
+    dist.barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += 1000 + rank
+    dist.barrier()
+    dt = time.perf_counter() - t0 + 1e-3 * (rank + 1)
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    work = torch.tensor([float(units)], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "stub_units_per_sec", "value": work.item() / tmax.item(), "unit": "units/s",
+                          "n_gpus": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup, "data": "stub",
+                          "units": work.item(), "ranks_seen": dist.get_world_size()}), flush=True)
+    dist.destroy_process_group()
+
+
+K3_INFO = {
+    "wino": dict(kernel="k_cnn_forward_wino", dtype="f32",
+                 algorithm="Winograd F(2x2,3x3) for the 3x3 convolutions on v_mfma_f32_16x16x4_f32; achieved/frac in "
+                           "algorithmic (direct-convolution) flops, 41.62 MFLOP per leaf"),
+    "split": dict(kernel="k_cnn_forward_split",
+                  dtype="f32 via 3 x f16 MFMA products on hi/lo split operands, f32 accumulation, per-position dynamic range",
+                  algorithm="direct implicit GEMM on v_mfma_f32_32x32x16_f16; every fp32 product a*w as hi*hi + hi*lo + lo*hi "
+                            "of the fp16 halves (22 mantissa bits), fp32 accumulation; activations rescaled per position and "
+                            "layer by a power of two so that no half leaves fp16's range"),
+}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,42 +242,58 @@ def main(argv=None):
     ap.add_argument("--cohorts", type=int, default=0, help="slot ranges searched on their own HIP streams (0 = engine default)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event kernel timing in the timed region")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around the tree-step launches too (kernel_time_ms)")
-    ap.add_argument("--k3", choices=["wino", "split"], default="wino",
-                    help="wino: the product kernel (Winograd, fp32 MFMA); split: the experimental kernel (az_cnn_split.hip: "
-                         "fp32 products split over fp16 MFMA, fp32 accumulation)")
-    ap.add_argument("--no-experimental", action="store_true",
-                    help="skip the short extra run that reports the split kernel's rate under `experimental_k3_split_f16`")
+    ap.add_argument("--k3", choices=["wino", "split"], default=DEFAULT_K3,
+                    help="leaf-evaluation kernel of the headline run.  wino: Winograd on fp32 MFMA (az_cnn_wino.hip); split: "
+                         "fp32 products as three fp16 MFMA products on split operands, fp32 accumulation (az_cnn_split.hip)")
+    ap.add_argument("--no-second-leg", "--no-experimental", dest="no_second_leg", action="store_true",
+                    help="skip the run of the other K3 kernel that is reported beside the headline (N = 1 only)")
     ap.add_argument("--mode", choices=["rolling", "lockstep"], default="rolling",
                     help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
                          "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed de-synchronising steps before warm-up: -1 = staggered start over 34 steps, then until as many "
+                         "games have finished as there are slots (at most 136 steps); 0 = none (all slots start at ply 0 "
+                         "together); n > 0 = staggered start, n steps in all")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks as child processes of this one even for --gpus 1 (a 1-rank RCCL group)")
+    ap.add_argument("--workload", choices=["selfplay", "stub"], default="selfplay", help=argparse.SUPPRESS)
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if (args.gpus > 1 or args.launch) and "RANK" not in os.environ:
+        # not under torchrun: be the launcher (this process never touches the GPU)
+        sys.exit(launch_ranks(args.gpus, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs"
+                         % (args.gpus, world, world, args.gpus))
+    if args.workload == "stub":
+        return run_stub(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local)
 
     from alphazero_amd.collector import ReplaySink, TrajectoryGatherer
     from alphazero_amd.engine import SelfPlayEngine
 
     G, S = args.games, args.playouts
+    dev = torch.device("cuda", local)
     blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
-    # The engine comes first: a process has 4 hardware queues (GPU_MAX_HW_QUEUES) and HIP hands them to streams in
+    # The engine comes first: a process has few hardware queues (GPU_MAX_HW_QUEUES) and HIP hands them to streams in
     # creation order, so the engine's stream and its three cohort streams must exist before RCCL and
     # torch.distributed create theirs -- cohort streams that share a queue serialise their K3 launches (measured
     # under torch.distributed.run with the group initialised first: 374 ms per step instead of 280).
     def make_engine(k3):
+        # global game ids: rank + world * k, so the RNG streams of a job's games do not depend on how it is split
         e = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                            reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
-                           game_id_base=rank * (1 << 40), n_cohorts=args.cohorts)
-        if k3 == "split":      # the library reads the switch when the weights are loaded
-            os.environ["AZ_K3_SPLIT"] = "1"
-        try:
-            e.load_net(blob)
-        finally:
-            os.environ.pop("AZ_K3_SPLIT", None)
+                           game_id_base=rank, game_id_stride=world, n_cohorts=args.cohorts)
+        e.load_net(blob, kernel=k3)
         return e
 
     eng = make_engine(args.k3)
@@ -195,53 +301,112 @@ def main(argv=None):
     # one-rank launch on a one-GPU box walks the same barrier / all-reduce code as the N-GPU job
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
-    sink = ReplaySink("Connect4", capacity=1 << 20, device=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but RCCL reports %d ranks" % (args.gpus, dist.get_world_size()))
+    sink = ReplaySink("Connect4", capacity=1 << 20, device=dev)
 
-    def barrier():
+    def all_min(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def measure(eng, k3, steps, warmup):
+        """pre-roll, warm-up and the timed window on one engine -> the numbers of one leg"""
+        gather = TrajectoryGatherer(eng, device=dev)
+
+        def barrier():
+            if use_dist:
+                dist.barrier()
+            eng.sync()
+            torch.cuda.synchronize()
+
+        def one_step():
+            if args.mode == "rolling":
+                eng.selfplay_rounds(S, temp=1.0, first_n_steps=10, refill=True)
+            else:
+                eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
+            eng.sync()
+            recs = gather.gather()          # pack on device -> all_gather (RCCL) -> records of every rank
+            sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
+
+        # ---- untimed pre-roll: slot g's first game starts at step g % T0, i.e. the starts are spread evenly over one mean
+        # game length; then play on until G games have finished (every rank: the steps hold collectives)
+        pre_steps = 0
+        if args.preroll != 0:
+            T0 = 34 if args.preroll < 0 else max(1, min(34, args.preroll))
+            limit = 4 * T0 if args.preroll < 0 else args.preroll
+            start_step = np.arange(G) % T0
+            eng.reset_stats()
+            while pre_steps < limit:
+                if pre_steps < T0:
+                    eng.set_active((start_step <= pre_steps).astype(np.uint8))
+                one_step()
+                pre_steps += 1
+                if args.preroll < 0 and pre_steps >= T0 and all_min(eng.stats()["games_finished"]) >= G:
+                    break
+        for _ in range(warmup):
+            one_step()
+        eng.reset_stats()
+        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all else 2))   # 2: HIP events around the K3 launches only
+        stored0 = sink.total_stored
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = eng.get_profile()
+        st = eng.stats()
+        eng.set_profiling(False)
+        # aggregate over ranks: MAX time, SUM of work
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        work = torch.tensor([st["plies"], st["playouts"], st["games_finished"], st["leaf_evals"], st["levels"],
+                             st["terminal_hits"]], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.barrier()
-        eng.sync()
-        torch.cuda.synchronize()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(work, op=dist.ReduceOp.SUM)
+        r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term"), [float(x) for x in work.tolist()]))
+        r.update(dt=float(tmax.item()), prof=prof, stored=sink.total_stored - stored0, pre_steps=pre_steps, k3=k3)
+        return r
 
-    def one_step():
-        if args.mode == "rolling":
-            eng.selfplay_rounds(S, temp=1.0, first_n_steps=10, refill=True)
+    def roofline(m, k3):
+        cnn = m["prof"]["cnn"]
+        evals_rank = m["evals"] / world
+        cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
+        leaves_per_launch = evals_rank / max(cnn["launches"], 1)
+        # K3 launches of different cohorts run concurrently on their own streams, so the time the kernel occupies the
+        # GPU is the UNION of the launches' [start, stop] intervals (HIP events on the launch streams), not their sum.
+        # achieved = FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the launches do
+        # not overlap, i.e. --cohorts 1).
+        alg = FLOP_PER_LEAF * evals_rank / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
+        info = K3_INFO[k3]
+        if k3 == "split":
+            # priced on the pipe it runs on: EXECUTED fp16 MFMA flops (3 per algorithmic flop) against the dense fp16 peak;
+            # the fp32-equivalent (algorithmic) rate is reported beside it
+            roof = {"bound": "mfma", "kernel": info["kernel"], "achieved": 3 * alg, "peak": PEAK_F16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": 3 * alg / PEAK_F16_MFMA_TFLOPS, "traffic": K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH,
+                    "traffic_source": K3_SPLIT_TRAFFIC_SOURCE,
+                    "fp32_equivalent_tflops": alg, "fp32_equivalent_frac_of_f32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS,
+                    "executed_flop_per_leaf": SPLIT_FLOP_PER_LEAF, "algorithm": info["algorithm"]}
         else:
-            eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
-        eng.sync()
-        recs = gather.gather()          # pack on device -> all_gather (RCCL) -> records of every rank
-        sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
+            roof = {"bound": "mfma", "kernel": info["kernel"], "achieved": alg,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
+                    "algorithm": info["algorithm"], "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
+                    "executed_frac": alg * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS}
+        roof.update({"avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch, "launches": cnn["launches"],
+                     "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"], "concurrent_cohorts": eng.n_cohorts,
+                     "achieved_per_launch": (3 if k3 == "split" else 1) * FLOP_PER_LEAF * leaves_per_launch
+                                            / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12})
+        return roof
 
-    for _ in range(args.warmup):
-        one_step()
-    eng.reset_stats()
-    eng.set_profiling(0 if args.no_profile else (1 if args.profile_all else 2))   # 2: HIP events around the K3 launches only
-    g0, _ = eng.traj_count()
-    stored0 = sink.total_stored
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = eng.get_profile()
-    st = eng.stats()
-    eng.set_profiling(False)
+    m = measure(eng, args.k3, args.steps, args.warmup)
 
-    # aggregate over ranks: MAX time, SUM of work
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    work = torch.tensor([st["plies"], st["playouts"], st["games_finished"], st["leaf_evals"], st["levels"],
-                         st["terminal_hits"]], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(work, op=dist.ReduceOp.SUM)
-    dt_all = float(tmax.item())
-    plies, playouts, finished, evals, levels, term = [float(x) for x in work.tolist()]
-
-    # mean plies per game, untimed and unbiased: one complete cohort (every game started at a reset is played to its
-    # end, no refill), so short games are not over-represented the way they are among the first finishers.
+    # mean plies per game for the steady-state estimate, untimed and unbiased: one complete cohort (every game started
+    # at a reset is played to its end, no refill), so short games are not over-represented as among the first finishers.
     if args.mean_plies > 0:  # profiling runs: skip the cohort so that every CNN launch in the trace is a full batch
         mean_len = args.mean_plies
     else:
@@ -253,53 +418,34 @@ def main(argv=None):
         mean_len = cp / cg
 
     if rank == 0:
-        games_s = (plies / dt_all) / mean_len
-        cnn = prof["cnn"]
-        cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
-        leaves_per_launch = (evals / world) / max(cnn["launches"], 1)
-        # K3 launches of different cohorts run concurrently on their own streams, so the time the kernel occupies the
-        # GPU is the UNION of the launches' [start, stop] intervals (HIP events on the launch streams), not their sum.
-        # achieved = algorithmic FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the
-        # launches do not overlap, i.e. --cohorts 1).
-        achieved = FLOP_PER_LEAF * (evals / world) / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
-        if args.k3 == "split":
-            # the split kernel is priced on the pipe it runs on: executed fp16 MFMA flops (3 per algorithmic flop) against
-            # the dense fp16 peak; `algorithmic_tflops` keeps the 41.62 MFLOP-per-leaf figure next to it
-            roof = {"bound": "mfma", "kernel": "k_cnn_forward_split", "achieved": 3 * achieved, "peak": PEAK_F16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                    "algorithmic_tflops": achieved, "executed_flop_per_leaf": SPLIT_FLOP_PER_LEAF,
-                    "algorithm": "direct implicit GEMM on v_mfma_f32_16x16x32_f16; every fp32 product as 3 fp16 products "
-                                 "on split operands, fp32 accumulation"}
-        else:
-            roof = {"bound": "mfma", "kernel": "k_cnn_forward_wino", "achieved": achieved,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
-                    "algorithm": "Winograd F(2x2,3x3) for the 3x3 convolutions; achieved/frac in algorithmic "
-                                 "(direct-convolution) flops, 41.62 MFLOP per leaf",
-                    "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
-                    "executed_frac": achieved * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS}
-        roof.update({"avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch, "launches": cnn["launches"],
-                     "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"], "concurrent_cohorts": eng.n_cohorts,
-                     "achieved_per_launch": FLOP_PER_LEAF * leaves_per_launch / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12})
-        depth = levels / max(playouts, 1)
+        games_s = m["finished"] / m["dt"]           # games that finish inside the window / wall
+        est = (m["plies"] / m["dt"]) / mean_len
         out = {
             "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_all / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.k3 == "wino" else "f32 (products as 3 x f16 MFMA on split operands, f32 accumulation)",
-            "data": "synthetic",
-            "sims_per_sec": playouts / dt_all,
+            "dtype": K3_INFO[args.k3]["dtype"], "data": "synthetic",
+            "value_steady_state_estimate": est,
+            "sims_per_sec": m["playouts"] / m["dt"],
             "config": {"workload": "Connect4 CNN self-play, %d concurrent games/GPU x %d playouts/move, real "
                                    "AZ_Connect4_CNN_current weights, Dirichlet 0.7, random flips, tree reuse "
                                    "(BASELINE configs[2]%s)" % (G, S, "; trajectories all-gathered over RCCL into "
                                                                 "ReplayBuffer tensors" if world > 1 else ""),
-                       "mode": args.mode, "k3": args.k3, "games_per_gpu": G, "playouts_per_move": S, "mean_plies_per_game": mean_len,
-                       "games_finished_in_window": finished, "slot_plies_in_window": plies,
-                       "leaf_evals": evals, "terminal_hits": term, "mean_tree_depth": depth,
-                       "plies_stored_in_replay": sink.total_stored - stored0,
+                       "mode": args.mode, "k3": args.k3, "games_per_gpu": G, "playouts_per_move": S,
+                       "launcher": ("bench.py (self-launched ranks)" if os.environ.get("AZ_BENCH_SELF_LAUNCHED")
+                                    else ("torch.distributed.run" if use_dist else "single process")),
+                       "rccl_ranks": dist.get_world_size() if use_dist else None,
+                       "preroll_steps_untimed": m["pre_steps"],
+                       "preroll": "staggered first games over 34 steps, then until >= games_per_gpu games finished on every rank"
+                                  if args.preroll < 0 else ("none" if args.preroll == 0 else "staggered, fixed length"),
+                       "mean_plies_per_game": mean_len,
+                       "games_finished_in_window": m["finished"], "slot_plies_in_window": m["plies"],
+                       "leaf_evals": m["evals"], "terminal_hits": m["term"],
+                       "mean_tree_depth": m["levels"] / max(m["playouts"], 1),
+                       "plies_stored_in_replay": m["stored"],
                        "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
-            "roofline": roof,
-            "kernel_time_ms": {k: v["ms"] for k, v in prof.items()},
+            "roofline": roofline(m, args.k3),
+            "kernel_time_ms": {k: v["ms"] for k, v in m["prof"].items()},
             "box": _box_info(torch, local),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -307,28 +453,19 @@ def main(argv=None):
             out["config"]["x_cpu_port_1core"] = games_s / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["config"]["x_cpu_port_all_cores"] = games_s / out["cpu_baseline"]["all_cores"]["value"]
-        if world == 1 and args.k3 == "wino" and not args.no_experimental:
-            # the experimental K3 (opt-in, not the headline): the same workload for a short window on a second engine
+        if world == 1 and not args.no_second_leg:
+            # the other K3 kernel on the same workload, same pre-roll / warm-up / window, on a second engine
+            other = "wino" if args.k3 == "split" else "split"
             eng.close()
-            eng = make_engine("split")
-            gather = TrajectoryGatherer(eng, device=torch.device("cuda", local))
-            x_steps = args.steps          # the same window as the headline run
-            for _ in range(args.warmup):
-                one_step()
-            eng.reset_stats()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(x_steps):
-                one_step()
-            barrier()
-            xdt = time.perf_counter() - t0
-            xst = eng.stats()
-            out["experimental_k3_split_f16"] = {
-                "value": (xst["plies"] / xdt) / mean_len, "unit": "games/s", "sims_per_sec": xst["playouts"] / xdt,
-                "steps": x_steps, "ms_per_step": xdt / x_steps * 1e3, "switch": "AZ_K3_SPLIT=1 / bench.py --k3 split",
-                "note": "az_cnn_split.hip: fp32 products as 3 fp16 MFMA products on split operands, fp32 accumulation; "
-                        "same parity tests and tolerance as the product kernel; not the headline value"}
-        print(json.dumps(out))
+            eng = make_engine(other)
+            x = measure(eng, other, args.steps, args.warmup)
+            out["second_leg_" + ("fp32_winograd" if other == "wino" else "split_f16")] = {
+                "value": x["finished"] / x["dt"], "unit": "games/s",
+                "value_steady_state_estimate": (x["plies"] / x["dt"]) / mean_len,
+                "sims_per_sec": x["playouts"] / x["dt"], "steps": args.steps, "ms_per_step": x["dt"] / args.steps * 1e3,
+                "games_finished_in_window": x["finished"], "dtype": K3_INFO[other]["dtype"],
+                "roofline": roofline(x, other), "switch": "bench.py --k3 " + other}
+        print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -81,10 +81,13 @@ typedef struct az_config {
     int32_t move_mode;      /* AZ_MOVE_*                                                                  */
     int32_t max_plies;      /* per-game ply cap for arena sizing; 0 = game maximum                        */
     int64_t nodes_per_game; /* arena capacity in nodes; 0 = 1 + A*S*(reuse ? max_plies : 1)               */
-    uint64_t game_id_base;  /* global id of slot 0 (multi-GPU: rank * n_games), keys the RNG streams      */
+    uint64_t game_id_base;  /* global id of the first game (slot 0); keys the RNG streams; see game_id_stride */
     int32_t n_cohorts;      /* AZ_EVAL_CNN: slot ranges searched on their own HIP streams so that one range's  */
                             /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 2048 slots, 3 from 768), max 4.   */
                             /* Results do not depend on it (games are independent).                            */
+    uint64_t game_id_stride; /* the k-th game this engine starts (slots first, then refills) has the global id      */
+                            /* game_id_base + game_id_stride * k; 0 = 1.  Multi-GPU: base = rank, stride = world size, */
+                            /* so the ids 0..M-1 of a job's first M games are the same however the job is split.      */
 } az_config;
 
 typedef struct az_stats {
@@ -201,6 +204,11 @@ int az_selfplay_rounds(az_engine *e, int32_t n_rounds, double temp, int32_t firs
 int64_t az_selfplay_rolling(az_engine *e, int64_t n_games_target, double temp, int32_t first_n_steps, int64_t max_calls);
 /* total number of games az_selfplay_step's refill may start (0 = unlimited). */
 int az_set_game_target(az_engine *e, int64_t n_games_target);
+/* park (mask[g] == 0) or resume (mask[g] != 0) slots between calls: a parked slot takes no part in search, ply ends or
+ * refill and keeps its game and tree; a slot whose game is over stays idle until a refill restarts it.  No counterpart in
+ * the reference (one game at a time); az_selfplay parks surplus slots with it and bench.py staggers the first games so
+ * that the timed window sees slots at every game age.  Synchronises. */
+int az_set_active(az_engine *e, const uint8_t *mask);
 /* counts of finished games / recorded plies so far (synchronises). */
 int az_traj_count(az_engine *e, int64_t *n_games, int64_t *n_plies);
 /* copy recorded plies (finished games only, in completion order) to the host as flat arrays:
@@ -224,18 +232,34 @@ int az_traj_unpack_dev(int game, int64_t n, const void *packed_dev, float *state
 /* ---- K3: network --------------------------------------------------------------------------------------- */
 /* Upload the Connect4 CNN (Connect4/Network.py:30-55).  blob = every float32 tensor of the reference
  * state_dict concatenated in state_dict order (500106 floats); BatchNorm (eval) is folded here. */
-/* Environment switches read here (diagnostics / experiments, not part of the contract): AZ_K3_DIRECT=1 evaluates with the
- * direct fp32 implicit-GEMM kernel instead of the Winograd one; AZ_K3_SPLIT=1 with the experimental kernel that computes
- * every fp32 product as three fp16 MFMA products on split operands (fp32 accumulation). */
+/* A blob that holds a non-finite value is refused (AZ_ERR_ARG), unlike NetworkBase.load (NetworkBase.py:19-24), which
+ * carries on with whatever weights it has.  Calling it again on a live engine is the hot reload after a training step
+ * (Pipeline.py:87): later searches and forwards use the new weights. */
 int az_net_load(az_engine *e, const float *blob, size_t n_floats);
 /* CNN.forward + predict (Network.py:60-64,78-85) for n packed Connect4 positions:
  * logp [n][7], logv [n][3], probs [n][7], value [n].  Any output may be NULL. */
 int az_net_forward(az_engine *e, int64_t n, const uint64_t *states, float *logp, float *logv, float *probs,
                    float *value);
+/* Which kernel evaluates the network from the NEXT az_net_load on (no counterpart in the reference, which has one torch
+ * forward): AZ_K3_DEFAULT = the library's product kernel (or, for diagnostic runs, what the environment variable
+ * AZ_K3=wino|split|direct names); AZ_K3_WINO = Winograd F(2x2,3x3) on fp32 MFMA; AZ_K3_SPLIT = direct convolution with
+ * every fp32 product computed as three fp16 MFMA products on hi/lo split operands, fp32 accumulation, activations rescaled
+ * per position by a power of two; AZ_K3_DIRECT = direct convolution on fp32 MFMA (A/B baseline).
+ * All three meet the same 1e-4 contract against the reference's fp32 forward.  az_net_get_kernel: the kind in use. */
+#define AZ_K3_DEFAULT 0
+#define AZ_K3_WINO 1
+#define AZ_K3_SPLIT 2
+#define AZ_K3_DIRECT 3
+int az_net_set_kernel(az_engine *e, int kind);
+int az_net_get_kernel(az_engine *e);
 /* device-resident forward for bench.py / rocprof: states_dev [n][2], outputs device pointers, async. */
 int az_net_forward_dev(az_engine *e, int64_t n, const uint64_t *states_dev, float *probs_dev, float *value_dev);
 
 /* ---- test hooks ------------------------------------------------------------------------------------------ */
+/* replace every slot's tree by a root whose children, in this insertion order, have these actions and visit counts
+ * (arrays [G][A], n_children[G]), so that az_choose_moves can be checked against recorded outputs of
+ * AlphaZeroPlayer.get_action (player.py:101-111) for arbitrary (actions, visits). */
+int az_set_root_children(az_engine *e, const int32_t *actions, const int32_t *visits, const int32_t *n_children);
 /* TreeNode.PUCT (MCTS.py:47-55) evaluated by the device code path for n independent (Np, n, Q, prior). */
 int az_puct_batch(int device, double c_init, int32_t c_base, int64_t n, const int32_t *Np, const int32_t *nv,
                   const float *Q, const float *P, float *score);

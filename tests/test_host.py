@@ -102,3 +102,36 @@ def test_trajectory_gather_world_size_2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def _bench(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_bench_launcher_starts_n_ranks_stub_workload():
+    """`python bench.py --gpus 2` outside torchrun must start 2 ranks itself (the driver's SCALE command).  CPU stand-in:
+    the stub workload walks launcher -> rendezvous on 127.0.0.1 -> barrier -> MAX/SUM all-reduce -> rank 0's JSON line
+    over gloo; n_gpus is what the process group reports."""
+    import json
+    p = _bench(["--gpus", "2", "--workload", "stub", "--steps", "5", "--warmup", "0"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["units"] == 5 * 1000 + 5 * 1001 and d["steps"] == 5
+
+
+def test_bench_refuses_rank_count_mismatch():
+    """a 1-rank environment must never be reported as an N-GPU run"""
+    p = _bench(["--gpus", "2", "--workload", "stub"], {"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                                                       "MASTER_PORT": "29537"})
+    assert p.returncode != 0 and b"refusing" in p.stderr
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    p = _bench(["--gpus", "2", "--workload", "stub", "--steps", "1"], {"AZ_BENCH_STUB_FAIL_RANK": "1"})
+    assert p.returncode != 0
