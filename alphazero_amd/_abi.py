@@ -88,6 +88,7 @@ SIGNATURES = {
     "az_traj_unpack_dev": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "az_net_load": (C.c_int, [_vp, _vp, C.c_size_t]),
     "az_net_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "az_net_forward_static": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "az_net_set_kernel": (C.c_int, [_vp, C.c_int]),
     "az_net_get_kernel": (C.c_int, [_vp]),
     "az_net_forward_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -81,6 +81,39 @@ struct TmpBufs {
     }
 };
 
+// ---- az_net_forward_static: the staging memory of the allocation-free forward.  One file-scope device array; every
+// GPU the library runs on holds its own copy at its own address until the process ends, so the address is looked up once
+// per device (hipGetSymbolAddress with that device current) and only that pointer is ever used from host code.
+struct StaticStage {
+    u64 states[AZ_NET_FORWARD_STATIC_MAX * 2];
+    float logp[AZ_NET_FORWARD_STATIC_MAX * 7];
+    float logv[AZ_NET_FORWARD_STATIC_MAX * 3];
+    float probs[AZ_NET_FORWARD_STATIC_MAX * 7];
+    float value[AZ_NET_FORWARD_STATIC_MAX];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticStage)];   // 352 KiB
+constexpr int MAX_DEVICES = 64;
+static StaticStage* g_stage[MAX_DEVICES] = {nullptr};
+static std::mutex g_stage_mu;
+
+// device `dev` is current.  Called from az_engine_create, i.e. never from inside the allocation-free entry point's hot path.
+static int static_stage_init(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) {
+        set_error("device ordinal beyond the static staging table");
+        return AZ_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    if (g_stage[dev]) return AZ_OK;
+    void* p = nullptr;
+    AZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) {
+        set_error("hipGetSymbolAddress(scratch) returned a null address");
+        return AZ_ERR_HIP;
+    }
+    g_stage[dev] = reinterpret_cast<StaticStage*>(p);
+    return AZ_OK;
+}
+
 }  // namespace az
 
 using namespace az;
@@ -382,6 +415,7 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         return AZ_ERR_ARG;
     }
     AZ_TRY(use_device(cfg->device));
+    AZ_TRY(static_stage_init(cfg->device));
     az_engine* e = new az_engine();
     e->cfg = *cfg;
     e->gi = gi;
@@ -1210,6 +1244,37 @@ int az_net_forward(az_engine* e, int64_t n, const uint64_t* states, float* logp,
     if (logv) AZ_HIP(hipMemcpy(logv, dlv, n * 12, hipMemcpyDeviceToHost));
     if (probs) AZ_HIP(hipMemcpy(probs, dp, n * 28, hipMemcpyDeviceToHost));
     if (value) AZ_HIP(hipMemcpy(value, dv, n * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_net_forward_static(az_engine* e, int64_t n, const uint64_t* states, float* logp, float* logv, float* probs,
+                          float* value) {
+    AZ_CHECK_E(e);
+    if (!e->net) {
+        set_error("az_net_forward_static: call az_net_load first");
+        return AZ_ERR_NO_NET;
+    }
+    if (n < 0 || !states) return bad_arg("az_net_forward_static");
+    if (n > AZ_NET_FORWARD_STATIC_MAX) {
+        set_error("az_net_forward_static: " + std::to_string(n) + " positions exceed AZ_NET_FORWARD_STATIC_MAX (" +
+                  std::to_string(AZ_NET_FORWARD_STATIC_MAX) + "); use az_net_forward or split the batch");
+        return AZ_ERR_ARG;
+    }
+    if (n == 0) return AZ_OK;
+    StaticStage* st = g_stage[e->cfg.device];   // set by az_engine_create on this device
+    if (!st) {
+        set_error("az_net_forward_static: static staging memory was not initialised on this device");
+        return AZ_ERR_STATE;
+    }
+    // every byte the kernels read (n positions) is written here first and every output row of the n positions is
+    // written by the kernel, so nothing in the array has to start at zero; rows beyond n keep the last call's contents
+    AZ_HIP(hipMemcpyAsync(st->states, states, (size_t)n * 16, hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(cnn_forward(e->net, n, st->states, st->logp, st->logv, st->probs, st->value, e->stream));
+    if (logp) AZ_HIP(hipMemcpyAsync(logp, st->logp, (size_t)n * 28, hipMemcpyDeviceToHost, e->stream));
+    if (logv) AZ_HIP(hipMemcpyAsync(logv, st->logv, (size_t)n * 12, hipMemcpyDeviceToHost, e->stream));
+    if (probs) AZ_HIP(hipMemcpyAsync(probs, st->probs, (size_t)n * 28, hipMemcpyDeviceToHost, e->stream));
+    if (value) AZ_HIP(hipMemcpyAsync(value, st->value, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
     return AZ_OK;
 }
 

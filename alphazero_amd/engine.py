@@ -205,6 +205,15 @@ class SelfPlayEngine:
         check(self.L.az_net_forward(self.h, n, ptr(s), ptr(logp), ptr(logv), ptr(probs), ptr(value)))
         return logp, logv, probs, value
 
+    def net_forward_static(self, states):
+        """az_net_forward_static: the same forward without any device allocation (at most 4096 positions)"""
+        s = _abi.as_u64(states).reshape(-1, 2)
+        n = s.shape[0]
+        logp, logv = np.zeros((n, 7), np.float32), np.zeros((n, 3), np.float32)
+        probs, value = np.zeros((n, 7), np.float32), np.zeros((n, 1), np.float32)
+        check(self.L.az_net_forward_static(self.h, n, ptr(s), ptr(logp), ptr(logv), ptr(probs), ptr(value)))
+        return logp, logv, probs, value
+
     def stats(self):
         st = _abi.az_stats()
         check(self.L.az_get_stats(self.h, C.byref(st)))

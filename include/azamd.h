@@ -240,6 +240,16 @@ int az_net_load(az_engine *e, const float *blob, size_t n_floats);
  * logp [n][7], logv [n][3], probs [n][7], value [n].  Any output may be NULL. */
 int az_net_forward(az_engine *e, int64_t n, const uint64_t *states, float *logp, float *logv, float *probs,
                    float *value);
+/* az_net_forward WITHOUT ANY ALLOCATION.  No counterpart in the reference; it is for callers that cannot allocate
+ * device memory: tight serving loops (CNN.predict once per move, NetworkPlayer arenas), harnesses that forbid hipMalloc,
+ * code around HIP graph capture.  az_net_forward hipMallocs and frees five staging buffers per call; this variant stages
+ * the n positions and the four outputs in a fixed device array inside the library (352 KiB per GPU, held until the
+ * process ends) and calls no hipMalloc / hipFree.  Same arguments, same kernels, bit-identical outputs.
+ * n > AZ_NET_FORWARD_STATIC_MAX is AZ_ERR_ARG.  Every call on a GPU shares that GPU's array: calls that overlap in time
+ * on one GPU (two host threads, two engines) race -- serialise them. */
+#define AZ_NET_FORWARD_STATIC_MAX 4096
+int az_net_forward_static(az_engine *e, int64_t n, const uint64_t *states, float *logp, float *logv, float *probs,
+                          float *value);
 /* Which kernel evaluates the network from the NEXT az_net_load on (no counterpart in the reference, which has one torch
  * forward): AZ_K3_DEFAULT = the library's product kernel (or, for diagnostic runs, what the environment variable
  * AZ_K3=wino|split|direct names); AZ_K3_WINO = Winograd F(2x2,3x3) on fp32 MFMA; AZ_K3_SPLIT = direct convolution with
