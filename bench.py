@@ -251,9 +251,10 @@ def main(argv=None):
                     help="rolling: az_selfplay_rounds (a step = 500 rounds; games advance individually, leaf batches stay "
                          "full); lockstep: az_selfplay_step (a step = one ply of every slot)")
     ap.add_argument("--preroll", type=int, default=-1,
-                    help="untimed de-synchronising steps before warm-up: -1 = staggered start over 34 steps, then until as many "
-                         "games have finished as there are slots (at most 136 steps); 0 = none (all slots start at ply 0 "
-                         "together); n > 0 = staggered start, n steps in all")
+                    help="untimed de-synchronising steps before warm-up: -1 = first games staggered over 22 steps (one mean game "
+                         "duration: a slot plays ~1.5 plies per step), then until twice as many games have finished as there "
+                         "are slots (at most 132 steps); 0 = none (all slots start at ply 0 together); n > 0 = staggered "
+                         "start, n steps in all")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks as child processes of this one even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--workload", choices=["selfplay", "stub"], default="selfplay", help=argparse.SUPPRESS)
@@ -333,11 +334,14 @@ def main(argv=None):
             sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
 
         # ---- untimed pre-roll: slot g's first game starts at step g % T0, i.e. the starts are spread evenly over one mean
-        # game length; then play on until G games have finished (every rank: the steps hold collectives)
+        # game DURATION (33 plies at ~1.5 plies per slot per step: terminal playouts are finished in place, so a slot gets
+        # through more than one move's playouts in 500 rounds); then two more generations of games, after which what is
+        # left of the start-up oscillation of the finishing rate is below a per cent (game lengths vary by ~25 %).
+        # Every rank runs the same number of steps (they hold collectives).
         pre_steps = 0
         if args.preroll != 0:
-            T0 = 34 if args.preroll < 0 else max(1, min(34, args.preroll))
-            limit = 4 * T0 if args.preroll < 0 else args.preroll
+            T0 = 22 if args.preroll < 0 else max(1, min(22, args.preroll))
+            limit = 6 * T0 if args.preroll < 0 else args.preroll
             start_step = np.arange(G) % T0
             eng.reset_stats()
             while pre_steps < limit:
@@ -345,7 +349,7 @@ def main(argv=None):
                     eng.set_active((start_step <= pre_steps).astype(np.uint8))
                 one_step()
                 pre_steps += 1
-                if args.preroll < 0 and pre_steps >= T0 and all_min(eng.stats()["games_finished"]) >= G:
+                if args.preroll < 0 and pre_steps >= T0 and all_min(eng.stats()["games_finished"]) >= 2 * G:
                     break
         for _ in range(warmup):
             one_step()
@@ -436,7 +440,7 @@ def main(argv=None):
                                     else ("torch.distributed.run" if use_dist else "single process")),
                        "rccl_ranks": dist.get_world_size() if use_dist else None,
                        "preroll_steps_untimed": m["pre_steps"],
-                       "preroll": "staggered first games over 34 steps, then until >= games_per_gpu games finished on every rank"
+                       "preroll": "first games staggered over 22 steps, then until >= 2 x games_per_gpu games finished on every rank"
                                   if args.preroll < 0 else ("none" if args.preroll == 0 else "staggered, fixed length"),
                        "mean_plies_per_game": mean_len,
                        "games_finished_in_window": m["finished"], "slot_plies_in_window": m["plies"],
