@@ -58,8 +58,8 @@ struct CnnDev {
 struct Cnn {
     CnnDev d;
     std::vector<void*> allocs;
-    CnnW* wino = nullptr;  // the product kernel's weights; null only in the AZ_K3_DIRECT=1 diagnostic mode
-    CnnS* split = nullptr; // AZ_K3_SPLIT=1: the experimental split-fp16 kernel evaluates instead
+    CnnW* wino = nullptr;  // AZ_K3_WINO: Winograd form on fp32 MFMA
+    CnnS* split = nullptr; // AZ_K3_SPLIT (the product kernel): split-fp16 form; neither: the direct fp32 kernel of this file
 };
 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) are far inside the 1e-4 contract.

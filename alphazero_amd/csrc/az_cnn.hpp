@@ -1,7 +1,9 @@
-// az_cnn.hpp -- K3 interface: fused Connect4 policy/value CNN forward on fp32 MFMA.
-//   az_cnn_wino.hip : the product kernel (3x3 convolutions as Winograd F(2x2,3x3) products)
-//   az_cnn.hip      : dispatch + the direct implicit-GEMM kernel (kept for A/B measurement: AZ_K3_DIRECT=1)
-//   az_cnn_split.hip: experimental direct kernel on fp16 MFMA with split fp32 products (opt-in: AZ_K3_SPLIT=1)
+// az_cnn.hpp -- K3 interface: fused Connect4 policy/value CNN forward on MFMA.  Three kernels, one contract (1e-4 against
+// the reference's fp32 forward; golden vectors from all four reference checkpoints), selected with az_net_set_kernel:
+//   az_cnn_split.hip: the product kernel: direct convolution on fp16 MFMA, every fp32 product as three fp16 products on
+//                     hi/lo split operands, fp32 accumulation, per-position dynamic range (AZ_K3_SPLIT)
+//   az_cnn_wino.hip : the fp32-MFMA kernel (3x3 convolutions as Winograd F(2x2,3x3) products; AZ_K3_WINO)
+//   az_cnn.hip      : dispatch + the direct implicit-GEMM fp32-MFMA kernel (A/B baseline; AZ_K3_DIRECT)
 #pragma once
 #include <math.h>
 
@@ -11,10 +13,10 @@ namespace az {
 
 struct Cnn;   // device-resident folded weights of the selected kernel
 struct CnnW;  // Winograd-form weights
-struct CnnS;  // split-fp16 form (experimental, AZ_K3_SPLIT=1)
+struct CnnS;  // split-fp16 form
 
 // kind: AZ_K3_* of include/azamd.h (AZ_K3_DEFAULT: environment override, else the product kernel AZ_K3_PRODUCT)
-constexpr int AZ_K3_PRODUCT = AZ_K3_WINO;
+constexpr int AZ_K3_PRODUCT = AZ_K3_SPLIT;
 int cnn_create(const float* blob, size_t n_floats, int kind, Cnn** out);
 int cnn_kind(const Cnn* c);
 void cnn_destroy(Cnn* c);

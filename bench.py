@@ -55,7 +55,7 @@ SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product
 # HBM bytes per launch of the split kernel (PMC pass, profiles/r01_k3_split.txt: 17.4 MB = its 3.8 MB of split weights per XCD L2)
 K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = 17.4e6
 K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC pass, profiles/r01_k3_split.txt"
-DEFAULT_K3 = "wino"              # the headline kernel
+DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
