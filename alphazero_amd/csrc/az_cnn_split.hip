@@ -19,6 +19,7 @@
 // registers for the residual, t = SiLU(BN(conv3x3(x))) goes through the image and the 1x1 convolution is the same
 // routine with one tap.  Prototypes and measurements: tools/ubench/{conv,block}_split_f16.hip, tools/k3_accuracy.py,
 // tools/split_fp16_accuracy.py; DESIGN.md section 4.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -32,13 +33,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int SCH = 128, SNS = 4;                        // channels, positions per workgroup
-constexpr int SROWS = SNS * 63 + 9 + 20, SRS = SCH + 8;  // padded cells (7 rows x 9 per position, shared zero row) x halves
+constexpr int SCH = 128;                                 // channels
+constexpr int SRS = SCH + 8;                             // halves per image row (cell): 128 channels + 8 of padding (272 B apart)
 constexpr int SFRONT = 10;
-constexpr int SMF = 2, SNF = 3;                          // wave tile: 2 x 32 channels, 3 x 32 cells (2 x 2 waves)
+// image rows for NS positions per workgroup: 7 rows x 9 cells per position (board rows 1..6, columns 1..7; a position's bottom
+// zero row is the next one's top row) from row SFRONT on; cells run from row 20 to row 63 NS + 8 and a tap reaches 10 rows further
+__host__ __device__ constexpr int srows(int ns) { return ns * 63 + 19; }
+__host__ __device__ constexpr size_t split_lds(int ns) { return (size_t)2 * srows(ns) * SRS * 2; }
+constexpr int SNF = 3;                                   // wave tile: MF x 32 channels, 3 x 32 cells; MF = 2 with 4 waves (2 x 2), 1 with 8 waves (4 x 2)
 constexpr int SMFT = 4;                                  // 32-channel fragments in all
-constexpr int SCELLS = SNS * 42;
-constexpr size_t SPLIT_LDS = (size_t)2 * SROWS * SRS * 2;
+constexpr int SPLIT_DEFAULT_CFG = 44;
 
 struct CnnSDev {
     // tile weights, 32x32x16 fragments: [slice][kh][4 F][hi|lo][64 lanes] f16x8, lane = (channel 32 F + lane % 32,
@@ -62,6 +66,12 @@ __device__ inline float swave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+#ifdef AZ_K3S_DBG_TS   // diagnostic builds only (tools/k3_variants.sh, tools/k3s_stamps.py): shader-clock stamps of one wave
+__device__ unsigned long long g_split_ts[4][64];
+#define STAMP(i) do { if (blockIdx.x == 7 && lane == 0) g_split_ts[wave & 3][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define SMFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)      // the tile loops
 #define SMFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)    // the heads
 
@@ -69,7 +79,7 @@ __device__ inline float swave_sum(float v) {
 // + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
-template <int TAPS, int PER_TAP, bool LO_INPUT>
+template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
                                   int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
@@ -82,13 +92,23 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
         for (int kh = 0; kh < 2; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++) {
+#ifdef AZ_K3S_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
+                ah[b][kh][f] = (f16x8)((_Float16)(0.001f * (float)(sl + f)));
+                al[b][kh][f] = (f16x8)((_Float16)(0.002f * (float)(sl + kh)));
+#else
                 ah[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 0) * 64 + lane];
                 al[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 1) * 64 + lane];
+#endif
             }
 #pragma unroll
             for (int j = 0; j < SNF; j++) {
+#ifdef AZ_K3S_DBG_NOB   // diagnostic builds only: no LDS operand traffic, results are garbage
+                bh[b][kh][j] = (f16x8)((_Float16)(0.25f + (float)((brow[j] + toff) & 3)));
+                if (LO_INPUT) bl[b][kh][j] = (f16x8)((_Float16)(0.125f + (float)((brow[j] + toff) & 1)));
+#else
                 bh[b][kh][j] = *reinterpret_cast<const f16x8*>(hi + brow[j] + toff + 16 * kh);
                 if (LO_INPUT) bl[b][kh][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff + 16 * kh);
+#endif
             }
         }
     };
@@ -111,13 +131,38 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
                 for (int j = 0; j < SNF; j++) SMFMA(al[b][kh][f], bh[b][kh][j], acc[f][j]);
         }
     };
+    // One basic block per pair of slices: the fetches are UNCONDITIONAL (the slice index is clamped; the last pair of an even
+    // count fetches the last slice once more), because a conditional fetch is a block of 20 loads of its own during which the
+    // matrix pipe idles, and the scheduler cannot move loads across the branch.  Inside the block the loads of the next slice
+    // are dealt out one per MFMA (sched_group_barrier pipeline: MFMA, VMEM read | MFMA, DS read | ... | the remaining MFMAs),
+    // so a load instruction issues under an MFMA instead of in a burst between two slices.
+    constexpr int NA = 4 * SMF, NB = (LO_INPUT ? 4 : 2) * SNF, NM = 2 * (LO_INPUT ? 3 : 2) * SMF * SNF;
+    static_assert(NM >= NA + NB, "fewer MFMAs than loads per slice");
+    auto deal = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NA - NB, 0);
+    };
     fetch(0, 0);
-    for (int sl = 0; sl < NSL; sl += 2) {
-        if (sl + 1 < NSL) fetch(sl + 1, 1);
+#pragma unroll 1
+    for (int pr = 0; pr < NSL / 2; pr++) {
+        const int sl = 2 * pr;
+        fetch(sl + 1, 1);
         mfmas(0);
-        if (sl + 2 < NSL) fetch(sl + 2, 0);
-        if (sl + 1 < NSL) mfmas(1);
+        deal();
+        fetch(sl + 2 < NSL ? sl + 2 : NSL - 1, 0);
+        mfmas(1);
+        deal();
     }
+    if (NSL & 1) mfmas(0);   // the last slice of an odd count sits in buffer 0
 }
 
 // power-of-two scale that brings a position's largest magnitude m into [2^13, 2^14), and its inverse (both exact).
@@ -131,6 +176,7 @@ __device__ inline void range_scale(float m, float& sc, float& isc) {
 
 // this lane's values, times the position's scale -> split -> image, in place.  32x32 accumulator: register 4 q + r of
 // fragment f is channel ch0 + 32 f + 8 q + r (ch0 = 64 wa + 4 (lane / 32)) of cell column lane % 32
+template <int SMF>
 __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int ch0,
                                    const f32x16 (&val)[SMF][SNF], const float (&sc)[SNF]) {
 #pragma unroll
@@ -154,11 +200,20 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
             }
 }
 
-__global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
+// NS positions per workgroup, NW waves.  The 42 NS cells are cut into column groups of 96 (NWB of them), the 128 channels into
+// NW / NWB groups; a wave owns one (channel group, column group) tile.
+//   <4, 4>  one workgroup per CU, one wave per SIMD: wave tile 64 channels x 96 cells, up to 512 registers per lane
+//   <2, 4>  TWO workgroups per CU (80 KB of LDS and 256 registers per lane each): wave tile 32 channels x 96 cells (84 live).  A
+//           SIMD holds one wave of each workgroup, so one workgroup's epilogue arithmetic (SiLU, split, image stores) and operand
+//           waits run under the other's MFMAs -- a wave's own VALU work does not overlap its MFMAs on this chip
+//   <4, 8>  one workgroup of 8 waves (32 x 96 tiles): kept for measurement; all waves share the barriers, so nothing overlaps
+template <int NS, int NW>
+__global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
                                                               const u32* __restrict__ list, const u64* __restrict__ states,
                                                               float* __restrict__ logp, float* __restrict__ logv,
-                                                              float* __restrict__ probs, float* __restrict__ value) {
+                                                              float* __restrict__ probs, float* __restrict__ value, int desync) {
     extern __shared__ _Float16 lds[];
+    constexpr int SNS = NS, SCELLS = NS * 42, SROWS = srows(NS);
     __shared__ float hb[4][SCELLS];  // head activations: 3 policy channels, 1 value channel
     __shared__ float s_player[SNS];
     __shared__ long long s_slot[SNS];
@@ -168,8 +223,18 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
     const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
     const i64 s0 = (i64)blockIdx.x * SNS;
     if (s0 >= n) return;
+    constexpr int NWB = (SCELLS + 95) / 96, NWA = NW / NWB, SMF = 4 / NWA;   // waves along cells / channels; channel fragments per wave
+    static_assert(NWA * NWB == NW && NWA * SMF == 4, "wave grid must tile 128 channels x 96-cell column groups");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
-    for (int i = tid; i < SROWS * SRS; i += 256) reinterpret_cast<unsigned*>(lds)[i] = 0u;
+    if (NS == 2 && desync > 0) {
+        // Two workgroups share a CU and one wave of each shares every SIMD.  Started together they would walk the layers in
+        // step and their epilogues would coincide; the workgroup whose waves sit in the odd wave slots starts `desync` x 8 k
+        // cycles late, so that its arithmetic phases fall under the other's MFMA phases.
+        const u32 slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u;   // HW_ID.WAVE_ID bit 0
+        if (slot)
+            for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int i = tid; i < SROWS * SRS; i += NW * 64) reinterpret_cast<unsigned*>(lds)[i] = 0u;
     if (tid < 7 * SNS) (&s_amax[0][0])[tid] = 0u;
     __syncthreads();
     // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149): channels 0..2, exact in fp16
@@ -192,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
     }
     __syncthreads();
     // wave (wa, wb): channels 64 wa .. 64 wa + 63 (32-channel fragments 2 wa, 2 wa + 1) x cells 96 wb .. 96 wb + 95
-    const int wa = wave & 1, wb = wave >> 1, fbase = 2 * wa, l32 = lane & 31, kg = lane >> 5, ch0 = 64 * wa + 4 * kg;
+    const int wa = wave % NWA, wb = wave / NWA, fbase = SMF * wa, l32 = lane & 31, kg = lane >> 5, ch0 = 32 * SMF * wa + 4 * kg;
     int brow[SNF], crow[SNF], cpos[SNF];
     bool live[SNF];
     float sc[SNF], isc[SNF];   // scale of the image's current contents for this lane's columns (its position's), and 1/scale
@@ -252,14 +317,18 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SNF; j++) range_scale(__uint_as_float(s_amax[layer][cpos[j]]), sc[j], isc[j]);
-        store_image(hi, lo, crow, live, ch0, a, sc);
+        store_image<SMF>(hi, lo, crow, live, ch0, a, sc);
         __syncthreads();
     };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
+    STAMP(0);
     zero(acc);
-    conv_split<9, 1, false>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
+    STAMP(2);
     to_image(0, acc);
+    STAMP(3);
 
     // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
     for (int blk = 0; blk < 3; blk++) {
@@ -275,16 +344,24 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
 #pragma unroll
                     for (int r = 0; r < 4; r++) xres[f][j][4 * q + r] = ((float)xh[r] + (float)xl[r]) * isc[j];
                 }
+        STAMP(4 + 8 * blk);       // x read back for the residual
         zero(acc);
-        conv_split<9, 4, true>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<9, 4, true, SMF>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        STAMP(5 + 8 * blk);       // 3x3 convolution
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
+        STAMP(6 + 8 * blk);       // bias + SiLU
         to_image(1 + 2 * blk, acc);  // t
+        STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
-        conv_split<1, 4, true>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<1, 4, true, SMF>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
+        STAMP(9 + 8 * blk);
         to_image(2 + 2 * blk, acc);
+        STAMP(10 + 8 * blk);
     }
 
+    STAMP(28);
     // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment of
     // v_mfma_f32_16x16x32_f16 (cell = lane % 16, k group = lane / 16); the waves with wa == 0 do it for their 96 cells
     if (wa == 0) {
@@ -314,9 +391,10 @@ __global__ __launch_bounds__(256, 1) void k_cnn_forward_split(CnnSDev w, i64 n_h
         }
     }
     __syncthreads();
+    STAMP(29);
     // ---- Linear(126->7) / Linear(42->3) + log-softmax + predict() (Network.py:60-64,78-85): wave s, position s
     const int s = wave;
-    if (s0 + s >= n) return;
+    if (s >= SNS || s0 + s >= n) return;
     float pl[7], vl[3];
 #pragma unroll
     for (int a = 0; a < 7; a++) pl[a] = 0.f;
@@ -466,8 +544,12 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     if (rc == AZ_OK) rc = uploads(c, std::vector<float>(plb, plb + 7), &c->d.plin_b);
     if (rc == AZ_OK) rc = uploads(c, std::vector<float>(vlw, vlw + 3 * 42), &c->d.vlin_w);
     if (rc == AZ_OK) rc = uploads(c, std::vector<float>(vlb, vlb + 3), &c->d.vlin_b);
-    if (rc == AZ_OK && hipFuncSetAttribute((const void*)k_cnn_forward_split, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)SPLIT_LDS) != hipSuccess) {
+    if (rc == AZ_OK && (hipFuncSetAttribute((const void*)k_cnn_forward_split<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(4)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(4)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(2)) != hipSuccess)) {
         set_error("hipFuncSetAttribute(k_cnn_forward_split, dynamic LDS) failed");
         rc = AZ_ERR_HIP;
     }
@@ -479,6 +561,12 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
     return AZ_OK;
 }
 
+#ifdef AZ_K3S_DBG_TS
+extern "C" int az_dbg_split_stamps(unsigned long long* out /* [4][64] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_ts), sizeof(unsigned long long) * 4 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void cnns_destroy(CnnS* c) {
     if (!c) return;
     for (void* q : c->allocs) (void)hipFree(q);
@@ -487,9 +575,17 @@ void cnns_destroy(CnnS* c) {
 
 int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
                 float* logv, float* probs, float* value, hipStream_t st) {
-    const unsigned grid = (max_n + SNS - 1) / SNS;
-    if (grid == 0) return AZ_OK;
-    k_cnn_forward_split<<<dim3(grid), dim3(256), SPLIT_LDS, st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value);
+    if (max_n == 0) return AZ_OK;
+    static const char* cfg = getenv("AZ_K3_SPLIT_CFG");   // tuning hook: "44" (4 positions, 4 waves), "48", "24"
+    const int kc = cfg ? atoi(cfg) : SPLIT_DEFAULT_CFG;
+    static const char* dsy = getenv("AZ_K3_SPLIT_DESYNC");
+    const int desync = dsy ? atoi(dsy) : 0;
+    if (kc == 48)
+        k_cnn_forward_split<4, 8><<<dim3((max_n + 3) / 4), dim3(512), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+    else if (kc == 24)
+        k_cnn_forward_split<2, 4><<<dim3((max_n + 1) / 2), dim3(256), split_lds(2), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+    else
+        k_cnn_forward_split<4, 4><<<dim3((max_n + 3) / 4), dim3(256), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
