@@ -40,9 +40,8 @@ constexpr int SFRONT = 10;
 // zero row is the next one's top row) from row SFRONT on; cells run from row 20 to row 63 NS + 8 and a tap reaches 10 rows further
 __host__ __device__ constexpr int srows(int ns) { return ns * 63 + 19; }
 __host__ __device__ constexpr size_t split_lds(int ns) { return (size_t)2 * srows(ns) * SRS * 2; }
-constexpr int SNF = 3;                                   // wave tile: MF x 32 channels, 3 x 32 cells; MF = 2 with 4 waves (2 x 2), 1 with 8 waves (4 x 2)
 constexpr int SMFT = 4;                                  // 32-channel fragments in all
-constexpr int SPLIT_DEFAULT_CFG = 44;
+constexpr int SPLIT_DEFAULT_CFG = 34;   // measured in the bench (2 048 slots, 4 cohorts): 34 -> 822 games/s, 24 -> 696, 44 -> 677
 
 struct CnnSDev {
     // tile weights, 32x32x16 fragments: [slice][kh][4 F][hi|lo][64 lanes] f16x8, lane = (channel 32 F + lane % 32,
@@ -79,7 +78,7 @@ __device__ unsigned long long g_split_ts[4][64];
 // + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
-template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF>
+template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
                                   int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
@@ -176,7 +175,7 @@ __device__ inline void range_scale(float m, float& sc, float& isc) {
 
 // this lane's values, times the position's scale -> split -> image, in place.  32x32 accumulator: register 4 q + r of
 // fragment f is channel ch0 + 32 f + 8 q + r (ch0 = 64 wa + 4 (lane / 32)) of cell column lane % 32
-template <int SMF>
+template <int SMF, int SNF>
 __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)[SNF], const bool (&live)[SNF], int ch0,
                                    const f32x16 (&val)[SMF][SNF], const float (&sc)[SNF]) {
 #pragma unroll
@@ -206,6 +205,8 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
 //   <2, 4>  TWO workgroups per CU (80 KB of LDS and 256 registers per lane each): wave tile 32 channels x 96 cells (84 live).  A
 //           SIMD holds one wave of each workgroup, so one workgroup's epilogue arithmetic (SiLU, split, image stores) and operand
 //           waits run under the other's MFMAs -- a wave's own VALU work does not overlap its MFMAs on this chip
+//   <3, 4>  one workgroup per CU, 126 cells on 128 columns (1.6 % of the MFMA work on padding columns instead of 12.5 %): wave tile
+//           64 channels x 64 cells; a third more weight bytes per position
 //   <4, 8>  one workgroup of 8 waves (32 x 96 tiles): kept for measurement; all waves share the barriers, so nothing overlaps
 template <int NS, int NW>
 __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
@@ -223,8 +224,9 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
     const i64 s0 = (i64)blockIdx.x * SNS;
     if (s0 >= n) return;
-    constexpr int NWB = (SCELLS + 95) / 96, NWA = NW / NWB, SMF = 4 / NWA;   // waves along cells / channels; channel fragments per wave
-    static_assert(NWA * NWB == NW && NWA * SMF == 4, "wave grid must tile 128 channels x 96-cell column groups");
+    // waves along cells / channels; 32-cell and 32-channel fragments per wave
+    constexpr int NWB = NS == 2 ? 1 : 2, SNF = NS == 3 ? 2 : 3, NWA = NW / NWB, SMF = 4 / NWA;
+    static_assert(NWA * NWB == NW && NWA * SMF == 4 && NWB * SNF * 32 >= SCELLS, "wave grid must tile 128 channels x the cells");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
     if (NS == 2 && desync > 0) {
         // Two workgroups share a CU and one wave of each shares every SIMD.  Started together they would walk the layers in
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     float sc[SNF], isc[SNF];   // scale of the image's current contents for this lane's columns (its position's), and 1/scale
 #pragma unroll
     for (int j = 0; j < SNF; j++) {
-        int col = wb * 96 + j * 32 + l32;
+        int col = wb * (32 * SNF) + j * 32 + l32;
         live[j] = col < SCELLS;
         if (!live[j]) col = 0;
         const int s = col / 42, p = col % 42;
@@ -317,13 +319,13 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SNF; j++) range_scale(__uint_as_float(s_amax[layer][cpos[j]]), sc[j], isc[j]);
-        store_image<SMF>(hi, lo, crow, live, ch0, a, sc);
+        store_image<SMF, SNF>(hi, lo, crow, live, ch0, a, sc);
         __syncthreads();
     };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
-    conv_split<9, 1, false, SMF>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF, SNF>(w.w_stem, hi, lo, brow, lane, fbase, acc);
     STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
     STAMP(2);
@@ -346,14 +348,14 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
                 }
         STAMP(4 + 8 * blk);       // x read back for the residual
         zero(acc);
-        conv_split<9, 4, true, SMF>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<9, 4, true, SMF, SNF>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
         STAMP(5 + 8 * blk);       // 3x3 convolution
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
         STAMP(6 + 8 * blk);       // bias + SiLU
         to_image(1 + 2 * blk, acc);  // t
         STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
-        conv_split<1, 4, true, SMF>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<1, 4, true, SMF, SNF>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
         STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // v_mfma_f32_16x16x32_f16 (cell = lane % 16, k group = lane / 16); the waves with wa == 0 do it for their 96 cells
     if (wa == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 6; jj++) {
-            int col = wb * 96 + jj * 16 + n16;
+        for (int jj = 0; jj < 2 * SNF; jj++) {
+            int col = wb * (32 * SNF) + jj * 16 + n16;
             const bool lv = col < SCELLS;
             if (!lv) col = 0;
             const int sp = col / 42, p = col % 42;
@@ -549,7 +551,9 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
                         hipFuncSetAttribute((const void*)k_cnn_forward_split<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)split_lds(4)) != hipSuccess ||
                         hipFuncSetAttribute((const void*)k_cnn_forward_split<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)split_lds(2)) != hipSuccess)) {
+                                            (int)split_lds(2)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(3)) != hipSuccess)) {
         set_error("hipFuncSetAttribute(k_cnn_forward_split, dynamic LDS) failed");
         rc = AZ_ERR_HIP;
     }
@@ -582,6 +586,8 @@ int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32
     const int desync = dsy ? atoi(dsy) : 0;
     if (kc == 48)
         k_cnn_forward_split<4, 8><<<dim3((max_n + 3) / 4), dim3(512), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+    else if (kc == 34)
+        k_cnn_forward_split<3, 4><<<dim3((max_n + 2) / 3), dim3(256), split_lds(3), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
     else if (kc == 24)
         k_cnn_forward_split<2, 4><<<dim3((max_n + 1) / 2), dim3(256), split_lds(2), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
     else

@@ -37,6 +37,41 @@ def kernel_stats(db):
         print("%-70s %14.1f %14.1f %8.2fx" % (name.split("(")[0][-70:], busy / 1e3, tot / 1e3, tot / max(busy, 1)))
 
 
+def chain_stats(db):
+    """per HIP stream (= engine cohort): how one round of the rolling self-play spends its time.  A cohort's round is the
+    chain K3 launch -> tree step -> next K3 launch; the gaps are the time between a kernel's end and its successor's start."""
+    c = sqlite3.connect(db)
+    cols = [d[0] for d in c.execute("select * from kernels limit 1").description]
+    key = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+    print("# columns of the kernel view:", ", ".join(cols))
+    if key is None:
+        return
+    rows = list(c.execute("select %s, name, start, end from kernels order by start" % key))
+    by = {}
+    for q, name, a, b in rows:
+        by.setdefault(q, []).append((a, b, "k3" if "cnn_forward" in name else ("tree" if "tree_step" in name else "other")))
+    print("# per %s: kernel durations and the gaps inside the K3 -> tree step -> K3 chain (microseconds)" % key)
+    print("%-10s %8s %10s %10s %12s %12s %12s" % (key, "rounds", "k3_avg", "tree_avg", "k3->tree", "tree->k3", "round"))
+    for q, seq in sorted(by.items()):
+        k3 = [b - a for a, b, t in seq if t == "k3"]
+        tr = [b - a for a, b, t in seq if t == "tree"]
+        g1, g2, rnd = [], [], []
+        last_k3_start = None
+        for (a0, b0, t0), (a1, b1, t1) in zip(seq, seq[1:]):
+            if t0 == "k3" and t1 == "tree":
+                g1.append(a1 - b0)
+            if t0 == "tree" and t1 == "k3":
+                g2.append(a1 - b0)
+        starts = [a for a, b, t in seq if t == "k3"]
+        rnd = [y - x for x, y in zip(starts, starts[1:])]
+        if len(k3) < 10:
+            continue
+        med = lambda v: sorted(v)[len(v) // 2] / 1e3 if v else 0.0
+        avg = lambda v: sum(v) / len(v) / 1e3 if v else 0.0
+        print("%-10s %8d %10.1f %10.1f %12.1f %12.1f %12.1f   (medians: k3 %.1f tree %.1f gaps %.1f %.1f round %.1f)" %
+              (q, len(k3), avg(k3), avg(tr), avg(g1), avg(g2), avg(rnd), med(k3), med(tr), med(g1), med(g2), med(rnd)))
+
+
 def pmc_stats(db):
     c = sqlite3.connect(db)
     cols = [d[0] for d in c.execute("select * from counters_collection limit 1").description]
@@ -55,5 +90,7 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--pmc" in sys.argv:
         pmc_stats(args[0])
+    elif "--chains" in sys.argv:
+        chain_stats(args[0])
     else:
         kernel_stats(args[0])
