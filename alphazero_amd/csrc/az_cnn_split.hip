@@ -78,12 +78,13 @@ __device__ unsigned long long g_split_ts[4][64];
 // + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
-template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF>
+template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
                                   int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
     // v_mfma_f32_32x32x16_f16: a slice of 32 channels is two k-steps of 16 (kh); A = 32 channels x 16 k, B = 16 k x 32 cells
-    f16x8 ah[2][2][SMF], al[2][2][SMF], bh[2][2][SNF], bl[2][2][SNF];
+    // NST operand register sets: slice s + NST - 1 is requested while slice s is multiplied
+    f16x8 ah[NST][2][SMF], al[NST][2][SMF], bh[NST][2][SNF], bl[NST][2][SNF];
     auto fetch = [&](int sl, int b) {
         const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
         const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
@@ -150,18 +151,23 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NM - NA - NB, 0);
     };
-    fetch(0, 0);
+    static_assert(NSL >= NST, "fewer slices than operand register sets");
+#pragma unroll
+    for (int b = 0; b + 1 < NST; b++) fetch(b, b);
 #pragma unroll 1
-    for (int pr = 0; pr < NSL / 2; pr++) {
-        const int sl = 2 * pr;
-        fetch(sl + 1, 1);
-        mfmas(0);
-        deal();
-        fetch(sl + 2 < NSL ? sl + 2 : NSL - 1, 0);
-        mfmas(1);
-        deal();
+    for (int t = 0; t < NSL / NST; t++) {
+        const int sl = NST * t;
+#pragma unroll
+        for (int b = 0; b < NST; b++) {
+            const int nx = sl + b + NST - 1;
+            fetch(nx < NSL ? nx : NSL - 1, (b + NST - 1) % NST);
+            mfmas(b);
+            deal();
+        }
     }
-    if (NSL & 1) mfmas(0);   // the last slice of an odd count sits in buffer 0
+    // the NSL % NST last slices sit in register sets 0 .. (their fetches were issued by the last trip of the loop)
+#pragma unroll
+    for (int b = 0; b < NSL % NST; b++) mfmas(b);
 }
 
 // power-of-two scale that brings a position's largest magnitude m into [2^13, 2^14), and its inverse (both exact).
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     if (s0 >= n) return;
     // waves along cells / channels; 32-cell and 32-channel fragments per wave
     constexpr int NWB = NS == 2 ? 1 : 2, SNF = NS == 3 ? 2 : 3, NWA = NW / NWB, SMF = 4 / NWA;
+    constexpr int NST = NS == 3 ? 3 : 2;   // operand register sets (the 64 x 64 tile leaves room for a third)
     static_assert(NWA * NWB == NW && NWA * SMF == 4 && NWB * SNF * 32 >= SCELLS, "wave grid must tile 128 channels x the cells");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
     if (NS == 2 && desync > 0) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
-    conv_split<9, 1, false, SMF, SNF>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF, SNF, NST>(w.w_stem, hi, lo, brow, lane, fbase, acc);
     STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
     STAMP(2);
@@ -348,14 +355,14 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
                 }
         STAMP(4 + 8 * blk);       // x read back for the residual
         zero(acc);
-        conv_split<9, 4, true, SMF, SNF>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<9, 4, true, SMF, SNF, NST>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
         STAMP(5 + 8 * blk);       // 3x3 convolution
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
         STAMP(6 + 8 * blk);       // bias + SiLU
         to_image(1 + 2 * blk, acc);  // t
         STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
-        conv_split<1, 4, true, SMF, SNF>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<1, 4, true, SMF, SNF, NST>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
         STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
