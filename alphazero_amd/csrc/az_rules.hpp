@@ -104,6 +104,12 @@ struct C4 {
         if (wx && wo) return winner_scan(s);
         return wx ? 1 : (wo ? -1 : 0);
     }
+    // winner of a position reached by ONE move from a position without a line: only the side that has just moved can
+    // have made one (the search only ever steps from non-terminal nodes).  hint: unused here.
+    AZ_HD static int move_hint(const State&) { return 0; }
+    AZ_HD static int winner_moved(const State& s, int) {
+        return (s.w[1] & TURN_FLAG) ? (has4(xs(s)) ? 1 : 0) : (has4(os(s)) ? -1 : 0);
+    }
     AZ_HD static bool full(const State& s) { return ((xs(s) | os(s)) & BOARD) == BOARD; }  // :76-77
     AZ_HD static u32 legal(const State& s) {  // :120-124: columns with an empty cell, bit per column
         u64 occ = xs(s) | os(s);
@@ -155,6 +161,15 @@ struct TTT {
             if ((o & pat[i]) == pat[i]) return -1;
         }
         return 0;
+    }
+    AZ_HD static bool line9(u32 b) {   // any of the 8 lines fully set, no branches
+        const u32 rows = b & (b >> 1) & (b >> 2) & 0x049, cols = b & (b >> 3) & (b >> 6) & 0x007;
+        const u32 dg = b & (b >> 4) & (b >> 8) & 1u, ad = (b >> 2) & (b >> 4) & (b >> 6) & 1u;
+        return (rows | cols | dg | ad) != 0;
+    }
+    AZ_HD static int move_hint(const State&) { return 0; }
+    AZ_HD static int winner_moved(const State& s, int) {   // see C4::winner_moved
+        return (s.w[0] & TURN_FLAG) ? (line9(xs(s)) ? 1 : 0) : (line9(os(s)) ? -1 : 0);
     }
     AZ_HD static bool full(const State& s) { return (xs(s) | os(s)) == 0x1FF; }
     AZ_HD static u32 legal(const State& s) { return ~(xs(s) | os(s)) & 0x1FF; }
@@ -210,6 +225,14 @@ struct NBTTT {
             if (w) return w;
         }
         return 0;
+    }
+    // see C4::winner_moved.  hint = the sub-board the move went into (curr of the position before the move): the only
+    // sub-board that can hold a line now, and only the mover's stones can form it
+    AZ_HD static int move_hint(const State& before) { return curr(before); }
+    AZ_HD static int winner_moved(const State& s, int b) {
+        if (b > 8) return 0;
+        const u32 sb = sub(s, b);
+        return (s.w[3] & TURN_FLAG) ? (TTT::line9(sb & 0x1FF) ? 1 : 0) : (TTT::line9(sb >> 9) ? -1 : 0);
     }
     // build-defined: terminal draw when the CURRENT sub-board is full
     // (NBTTT/dependency/Negamax.c:34, utils.c:88-97), not the reference env's all-81 test.

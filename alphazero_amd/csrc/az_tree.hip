@@ -58,7 +58,7 @@ __device__ inline typename G::State load_root_state(const Dev& d, int g) {
 //            probs = raw / left-to-right f32 sum(raw), value = (mix(h+64) >> 40) / 2^23 - 1.  Specified in DESIGN.md so that any
 //            implementation (the reference through a fake policy_value_fn, a CPU checker, this kernel) computes identical bits.
 template <class G>
-__device__ inline void eval_synthetic(int kind, u64 seed, const typename G::State& aug, float* probs, float& value) {
+__device__ inline void eval_synthetic(int kind, u64 seed, const typename G::State& aug, float* probs, float& value, int gl) {
     if (kind == AZ_EVAL_UNIFORM) {
         const float p = 1.0f / (float)G::A;
 #pragma unroll
@@ -68,11 +68,14 @@ __device__ inline void eval_synthetic(int kind, u64 seed, const typename G::Stat
         u64 h = seed;
 #pragma unroll
         for (int i = 0; i < G::W; i++) h = mix64(h ^ aug.w[i]);
+        // lane a of the group hashes action a (every lane used to hash all A of them); the raw values are then handed round
+        // so that every lane adds them up in the same left-to-right order as before
+        const float mine = (float)((mix64(h + (u64)gl + 1) >> 40) + 1) * (1.0f / 16777216.0f);
         float raw[G::A];
         float s = 0.f;
 #pragma unroll
         for (int a = 0; a < G::A; a++) {
-            raw[a] = (float)((mix64(h + (u64)a + 1) >> 40) + 1) * (1.0f / 16777216.0f);
+            raw[a] = __shfl(mine, a, G::LG);
             s = s + raw[a];
         }
 #pragma unroll
@@ -155,6 +158,7 @@ struct Leaf {
     u32 link;      // the leaf's link word (no children yet; action nibble set)
     u32 flags;     // bit0 terminal, bit1 flipped, bit2 unflipped board mirror-symmetric
     float tvalue;  // terminal value
+    int hint;      // G::move_hint of the position before the last step of the walk (meaningless at depth 0)
 };
 
 // MCTS.py:108-113 (select_leaf_node) for one game.  Stages (index, N, Q) of every node on the path in LDS.
@@ -163,7 +167,7 @@ __device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State&
                             u32 rlink, int gl, u32* p_idx, u32* p_N, float* p_Q) {
     constexpr int LG = G::LG;
     u32 node = root, Np = rN, link = rlink;
-    int depth = 0;
+    int depth = 0, hint = 0;
     if (gl == 0) {
         p_idx[0] = root;
         p_N[0] = rN;
@@ -189,11 +193,13 @@ __device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State&
             p_N[depth] = cN;
             p_Q[depth] = as_f(cQ);
         }
+        hint = G::move_hint(s);
         G::step(s, (int)link_action(cl));  // env.step(action), redundantly on every lane of the group
         Np = cN;
         link = cl;
     }
     Leaf lf;
+    lf.hint = hint;
     lf.node = node;
     lf.link = link;
     lf.depth = depth;
@@ -216,7 +222,9 @@ __device__ inline void leaf_prepare(const Dev& d, int g, const typename G::State
             flipped = rng_uniform(d.rng_seed, d.game_id[g], ctr, 1u) < 0.5f;
         }
     }
-    int w = G::winner(s);
+    // The root of a live game holds no line, and a walk only ever steps from non-terminal nodes: a line at the leaf was made
+    // by the last move, in the sub-board it went into (G::winner_moved; the full scan G::winner stays with the K1 API).
+    int w = lf.depth > 0 ? G::winner_moved(s, lf.hint) : 0;
     bool term = (w != 0) || G::full(s);
     aug = flipped ? G::flip(s) : s;
     lf.flags = (term ? 1u : 0u) | (flipped ? 2u : 0u) | (G::symmetric(s) ? 4u : 0u);
@@ -294,13 +302,19 @@ __device__ inline void finish(const Dev& d, int g, uint4* nodes, const typename 
 // ------------------------------------------------------------------------------------------------------------
 // Fused search: n_sims complete playouts per game in ONE launch (evaluator computed in-kernel).
 // ------------------------------------------------------------------------------------------------------------
-template <class G>
+// GPW = games per wavefront: 64 / LG fills every lane; fewer games per wave (down to one: the other lanes exit at once) put the
+// same games on MORE waves (a measurement hook: see pick_gpw).  Results do not depend on it (a game is touched only by its
+// own lane group).
+template <class G, int GPW>
 __global__ __launch_bounds__(256) void k_search_fused(Dev d, int n_sims) {
-    constexpr int LG = G::LG, GPB = 256 / LG;
+    constexpr int LG = G::LG, GPB = 4 * GPW;
+    static_assert(GPW * LG <= 64, "lane groups of one wave");
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ float s_Q[GPB][G::MAXD];
-    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= GPW * LG) return;
+    const int grp = wave * GPW + lane / LG, gl = lane % LG;
     const int g = blockIdx.x * GPB + grp;
     if (g >= d.G) return;
     if (!d.active[g]) return;
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(256) void k_search_fused(Dev d, int n_sims) {
         leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
         float probs[G::A], value = 0.f;
         if (!(lf.flags & 1u)) {
-            eval_synthetic<G>(d.evaluator, d.eval_seed, aug, probs, value);
+            eval_synthetic<G>(d.evaluator, d.eval_seed, aug, probs, value, gl);
             st_evals++;
         } else {
 #pragma unroll
@@ -393,6 +407,7 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
     if (!(flags & 8u)) return false;
     uint4* nodes = d.nodes + (i64)g * d.cap;
     Leaf lf;
+    lf.hint = 0;
     lf.depth = d.leaf_depth[g];
     lf.flags = flags & 7u;
     lf.tvalue = d.leaf_tvalue[g];
@@ -607,8 +622,9 @@ __device__ inline int nth_set_bit(u32 m, int n) {
 template <class G>
 __device__ inline int rollout(const Dev& d, int g, typename G::State r, u64 ctr, u32& plies) {
     const int player = G::turn(r);
+    int w = 0;   // the leaf handed in is not terminal; from there on only the last move can make a line
     for (int it = 0; it < 1000; it++) {
-        if (G::winner(r) != 0 || G::full(r)) break;
+        if (w != 0 || G::full(r)) break;
         const u32 legal = G::legal(r);
         const int nv = __popc(legal);
         int idx;
@@ -621,20 +637,24 @@ __device__ inline int rollout(const Dev& d, int g, typename G::State r, u64 ctr,
             idx = (int)(rng_uniform(d.rng_seed, d.game_id[g], ctr, 0x4000u + (u32)it) * (float)nv);
             idx = idx < nv ? idx : nv - 1;
         }
+        const int hint = G::move_hint(r);
         G::step(r, nth_set_bit(legal, idx));
+        w = G::winner_moved(r, hint);
         plies++;
     }
-    const int w = G::winner(r);
     return w == 0 ? 0 : (w == player ? 1 : -1);
 }
 
-template <class G>
+template <class G, int GPW>
 __global__ __launch_bounds__(256) void k_search_pure(Dev d, int n_sims) {
-    constexpr int LG = G::LG, GPB = 256 / LG;
+    constexpr int LG = G::LG, GPB = 4 * GPW;
+    static_assert(GPW * LG <= 64, "lane groups of one wave");
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ double s_Q[GPB][G::MAXD];
-    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= GPW * LG) return;
+    const int grp = wave * GPW + lane / LG, gl = lane % LG;
     const int g = blockIdx.x * GPB + grp;
     if (g >= d.G) return;
     if (!d.active[g]) return;
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(256) void k_search_pure(Dev d, int n_sims) {
         typename G::State s = rs;  // env.copy()
         // ---- select_leaf_node(env, UCT=True): MCTS.py:108-113 with TreeNode.UCT (MCTS.py:57-63)
         u32 node = root, Np = rN, link = rlink;
-        int depth = 0;
+        int depth = 0, hint = 0;
         if (gl == 0) {
             s_idx[grp][0] = root;
             s_N[grp][0] = rN;
@@ -687,11 +707,13 @@ __global__ __launch_bounds__(256) void k_search_pure(Dev d, int n_sims) {
                 s_N[grp][depth] = cN;
                 s_Q[grp][depth] = cN ? __hiloint2double((int)cz, (int)cy) : 0.0;
             }
+            hint = G::move_hint(s);
             G::step(s, (int)link_action(cl));
             Np = cN;
             link = cl;
         }
         Leaf lf;
+        lf.hint = hint;
         lf.node = node;
         lf.link = link;
         lf.depth = depth;
@@ -822,10 +844,29 @@ __global__ __launch_bounds__(256) void k_puct(i64 n, const i32* Np, const i32* n
 
 static inline int game_of(const Dev& d) { return d.game; }
 
+// games per wave of the fused searches.  Measured (tools/bench_configs.py; TicTacToe 4 096 x 100 / NBTTT 8 192 x 800, kernel time
+// per launch): 4 games per wave 0.45 / 10.3 ms, 2: 0.46 / 11.0, 1: 0.54 / 19.8 -- a launch lasts as long as ONE game's chain
+// of playouts, which more waves do not shorten, while lanes left idle cost issue slots.  So every lane is used;
+// AZ_TREE_GPW overrides (measurement hook).
+template <class GT>
+static int pick_gpw(const Dev&) {
+    constexpr int full = 64 / GT::LG;
+    static const char* env = getenv("AZ_TREE_GPW");
+    int gpw = env ? atoi(env) : full;
+    if (gpw < 1) gpw = 1;
+    if (gpw > full) gpw = full;
+    return gpw;
+}
+
 int launch_search_fused(const Dev& d, int n_sims, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
-        int gpb = 256 / GT::LG;
-        k_search_fused<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d, n_sims);
+        const int gpw = pick_gpw<GT>(d), gpb = 4 * gpw;
+        const dim3 grid((d.G + gpb - 1) / gpb), blk(256);
+        if (gpw >= 8) {
+            if constexpr (GT::LG <= 8) k_search_fused<GT, 8><<<grid, blk, 0, st>>>(d, n_sims);
+        } else if (gpw >= 4) k_search_fused<GT, 4><<<grid, blk, 0, st>>>(d, n_sims);
+        else if (gpw >= 2) k_search_fused<GT, 2><<<grid, blk, 0, st>>>(d, n_sims);
+        else k_search_fused<GT, 1><<<grid, blk, 0, st>>>(d, n_sims);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
@@ -833,8 +874,13 @@ int launch_search_fused(const Dev& d, int n_sims, hipStream_t st) {
 
 int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
     AZ_DISPATCH_GAME(game_of(d), {
-        constexpr int gpb = 256 / GT::LG;
-        k_search_pure<GT><<<dim3((d.G + gpb - 1) / gpb), dim3(256), 0, st>>>(d, n_sims);
+        const int gpw = pick_gpw<GT>(d), gpb = 4 * gpw;
+        const dim3 grid((d.G + gpb - 1) / gpb), blk(256);
+        if (gpw >= 8) {
+            if constexpr (GT::LG <= 8) k_search_pure<GT, 8><<<grid, blk, 0, st>>>(d, n_sims);
+        } else if (gpw >= 4) k_search_pure<GT, 4><<<grid, blk, 0, st>>>(d, n_sims);
+        else if (gpw >= 2) k_search_pure<GT, 2><<<grid, blk, 0, st>>>(d, n_sims);
+        else k_search_pure<GT, 1><<<grid, blk, 0, st>>>(d, n_sims);
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
