@@ -15,7 +15,7 @@
 //   A position's scale depends on that position only, so its result does not depend on its neighbours in the batch.
 // The activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
 // image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup; its 4 waves are a
-// 2 x 2 grid, a wave owns 64 output channels x 96 cells.  Inside a residual block a lane keeps its own entries of x in
+// 2 x 2 grid (64 output channels x 64 cells each in the default 3-position form).  A lane keeps its own entries of x in fp32
 // registers for the residual, t = SiLU(BN(conv3x3(x))) goes through the image and the 1x1 convolution is the same
 // routine with one tap.  Prototypes and measurements: tools/ubench/{conv,block}_split_f16.hip, tools/k3_accuracy.py,
 // tools/split_fp16_accuracy.py; DESIGN.md section 4.
@@ -78,7 +78,8 @@ __device__ unsigned long long g_split_ts[4][64];
 // + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
-template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST>
+// NKH: k-steps of 16 per slice that hold anything (the stem's 3 input planes sit in the first one)
+template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST, int NKH = 2>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
                                   int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
@@ -89,7 +90,7 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
         const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
         const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
+        for (int kh = 0; kh < NKH; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++) {
 #ifdef AZ_K3S_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
@@ -114,7 +115,7 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     };
     auto mfmas = [&](int b) {  // product by product: 6 independent accumulators between two uses of the same one
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
+        for (int kh = 0; kh < NKH; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++)
 #pragma unroll
@@ -136,7 +137,7 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     // matrix pipe idles, and the scheduler cannot move loads across the branch.  Inside the block the loads of the next slice
     // are dealt out one per MFMA (sched_group_barrier pipeline: MFMA, VMEM read | MFMA, DS read | ... | the remaining MFMAs),
     // so a load instruction issues under an MFMA instead of in a burst between two slices.
-    constexpr int NA = 4 * SMF, NB = (LO_INPUT ? 4 : 2) * SNF, NM = 2 * (LO_INPUT ? 3 : 2) * SMF * SNF;
+    constexpr int NA = 2 * NKH * SMF, NB = (LO_INPUT ? 2 : 1) * NKH * SNF, NM = NKH * (LO_INPUT ? 3 : 2) * SMF * SNF;
     static_assert(NM >= NA + NB, "fewer MFMAs than loads per slice");
     auto deal = [&]() {
 #pragma unroll
@@ -332,28 +333,26 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
-    conv_split<9, 1, false, SMF, SNF, NST>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF, SNF, NST, 1>(w.w_stem, hi, lo, brow, lane, fbase, acc);
     STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
     STAMP(2);
+    // this lane's own entries of x in fp32, kept for the residual while the image holds t (what the image holds is x rounded
+    // to the 22 bits of a hi / lo pair; the residual takes the unrounded value)
+    f32x16 xres[SMF][SNF];
+    auto keep = [&](const f32x16 (&a)[SMF][SNF]) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int j = 0; j < SNF; j++) xres[f][j] = a[f][j];
+    };
+    keep(acc);
     to_image(0, acc);
     STAMP(3);
 
     // ---- 3 residual blocks (Network.py:19-27): x = SiLU(x + BN(conv1x1(SiLU(BN(conv3x3(x))))))
     for (int blk = 0; blk < 3; blk++) {
-        f32x16 xres[SMF][SNF];  // this lane's own entries of x, kept for the residual while the image holds t
-#pragma unroll
-        for (int f = 0; f < SMF; f++)
-#pragma unroll
-            for (int j = 0; j < SNF; j++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int at = crow[j] + ch0 + 32 * f + 8 * q;
-                    const f16x4 xh = *reinterpret_cast<const f16x4*>(hi + at), xl = *reinterpret_cast<const f16x4*>(lo + at);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) xres[f][j][4 * q + r] = ((float)xh[r] + (float)xl[r]) * isc[j];
-                }
-        STAMP(4 + 8 * blk);       // x read back for the residual
+        STAMP(4 + 8 * blk);
         zero(acc);
         conv_split<9, 4, true, SMF, SNF, NST>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
         STAMP(5 + 8 * blk);       // 3x3 convolution
@@ -366,6 +365,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
+        keep(acc);
         to_image(2 + 2 * blk, acc);
         STAMP(10 + 8 * blk);
     }
