@@ -79,39 +79,55 @@ __device__ unsigned long long g_split_ts[4][64];
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
 // NKH: k-steps of 16 per slice that hold anything (the stem's 3 input planes sit in the first one)
-template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST, int NKH = 2>
-__device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, const _Float16* lo, const int (&brow)[SNF],
+// UNROLLED: every slice is its own copy of the code, so the tap offsets (LDS) and the slice offsets (weights) are immediates and
+// the loop carries no address arithmetic at all; the weights come through buffer loads (SGPR descriptor + lane offset VGPR +
+// scalar / immediate offset: no 64-bit vector adds).  LO_OFF: distance in halves from the hi plane to the lo plane.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST, int NKH = 2, bool UNROLLED = false>
+__device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, int lo_off, const int (&brow)[SNF],
                                   int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
     constexpr int NSL = TAPS * PER_TAP;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, NSL * 2 * SMFT * 2 * 1024, 0x00020000);
+    const int wvo = lane * 16 + fbase * 2048;   // this lane's bytes inside a (slice, k-step) block of 4 fragments x hi | lo
     // v_mfma_f32_32x32x16_f16: a slice of 32 channels is two k-steps of 16 (kh); A = 32 channels x 16 k, B = 16 k x 32 cells
     // NST operand register sets: slice s + NST - 1 is requested while slice s is multiplied
     f16x8 ah[NST][2][SMF], al[NST][2][SMF], bh[NST][2][SNF], bl[NST][2][SNF];
-    auto fetch = [&](int sl, int b) {
-        const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
-        const int toff = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS + cs * 32;
+    // operands of one slice into register set b: B from the image rows bb[j] (+ immediate k offset boff, in halves), A from the
+    // weight block at byte offset wso (uniform) of the layer
+    auto fetch_at = [&](const int (&bb)[SNF], int boff, int wso, int b) {
 #pragma unroll
         for (int kh = 0; kh < NKH; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++) {
 #ifdef AZ_K3S_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
-                ah[b][kh][f] = (f16x8)((_Float16)(0.001f * (float)(sl + f)));
-                al[b][kh][f] = (f16x8)((_Float16)(0.002f * (float)(sl + kh)));
+                ah[b][kh][f] = (f16x8)((_Float16)(0.001f * (float)(wso + f)));
+                al[b][kh][f] = (f16x8)((_Float16)(0.002f * (float)(wso + kh)));
 #else
-                ah[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 0) * 64 + lane];
-                al[b][kh][f] = w[((size_t)((sl * 2 + kh) * SMFT + fbase + f) * 2 + 1) * 64 + lane];
+                const u32x4 qh = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + (kh * SMFT + f) * 2048, 0);
+                const u32x4 ql = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + (kh * SMFT + f) * 2048 + 1024, 0);
+                ah[b][kh][f] = __builtin_bit_cast(f16x8, qh);
+                al[b][kh][f] = __builtin_bit_cast(f16x8, ql);
 #endif
             }
 #pragma unroll
             for (int j = 0; j < SNF; j++) {
 #ifdef AZ_K3S_DBG_NOB   // diagnostic builds only: no LDS operand traffic, results are garbage
-                bh[b][kh][j] = (f16x8)((_Float16)(0.25f + (float)((brow[j] + toff) & 3)));
-                if (LO_INPUT) bl[b][kh][j] = (f16x8)((_Float16)(0.125f + (float)((brow[j] + toff) & 1)));
+                bh[b][kh][j] = (f16x8)((_Float16)(0.25f + (float)((bb[j] + boff) & 3)));
+                if (LO_INPUT) bl[b][kh][j] = (f16x8)((_Float16)(0.125f + (float)((bb[j] + boff) & 1)));
 #else
-                bh[b][kh][j] = *reinterpret_cast<const f16x8*>(hi + brow[j] + toff + 16 * kh);
-                if (LO_INPUT) bl[b][kh][j] = *reinterpret_cast<const f16x8*>(lo + brow[j] + toff + 16 * kh);
+                bh[b][kh][j] = *reinterpret_cast<const f16x8*>(hi + bb[j] + boff + 16 * kh);
+                if (LO_INPUT) bl[b][kh][j] = *reinterpret_cast<const f16x8*>(hi + bb[j] + boff + 16 * kh + lo_off);
 #endif
             }
         }
+    };
+    auto tap_off = [](int tap) { return ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS; };
+    auto fetch = [&](int sl, int b) {
+        const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
+        int bb[SNF];
+#pragma unroll
+        for (int j = 0; j < SNF; j++) bb[j] = brow[j] + tap_off(tap);
+        fetch_at(bb, cs * 32, sl * (2 * SMFT * 2048), b);
     };
     auto mfmas = [&](int b) {  // product by product: 6 independent accumulators between two uses of the same one
 #pragma unroll
@@ -155,20 +171,51 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     static_assert(NSL >= NST, "fewer slices than operand register sets");
 #pragma unroll
     for (int b = 0; b + 1 < NST; b++) fetch(b, b);
+    if constexpr (UNROLLED && TAPS == 9 && PER_TAP == 4) {
+        // one trip per tap, its four slices unrolled (two register sets): the image rows of this tap and of the next one are
+        // kept as per-lane bases, so that a slice's operands are base + immediate; 2 SNF vector adds per tap, none per slice
+        static_assert(NST == 2, "the tap-unrolled form rotates two register sets");
+        int bcur[SNF], bnxt[SNF];
+#pragma unroll
+        for (int j = 0; j < SNF; j++) bcur[j] = brow[j] + tap_off(0), bnxt[j] = brow[j] + tap_off(1);
+        int wso = 0;
 #pragma unroll 1
-    for (int t = 0; t < NSL / NST; t++) {
-        const int sl = NST * t;
+        for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
-        for (int b = 0; b < NST; b++) {
-            const int nx = sl + b + NST - 1;
-            fetch(nx < NSL ? nx : NSL - 1, (b + NST - 1) % NST);
-            mfmas(b);
-            deal();
+            for (int cs = 0; cs < 4; cs++) {
+                if (cs < 3) fetch_at(bcur, (cs + 1) * 32, wso + (cs + 1) * (2 * SMFT * 2048), (cs + 1) & 1);
+                else fetch_at(bnxt, 0, tap < 8 ? wso + 4 * (2 * SMFT * 2048) : wso, 0);   // after the last tap: a valid slice again, unused
+                mfmas(cs & 1);
+                deal();
+            }
+            wso += 4 * (2 * SMFT * 2048);
+            const int t2 = tap + 2 < 9 ? tap + 2 : 8;
+#pragma unroll
+            for (int j = 0; j < SNF; j++) bcur[j] = bnxt[j], bnxt[j] = brow[j] + tap_off(t2);
         }
-    }
-    // the NSL % NST last slices sit in register sets 0 .. (their fetches were issued by the last trip of the loop)
+    } else if constexpr (UNROLLED) {
 #pragma unroll
-    for (int b = 0; b < NSL % NST; b++) mfmas(b);
+        for (int sl = 0; sl < NSL; sl++) {
+            if (sl + NST - 1 < NSL) fetch(sl + NST - 1, (sl + NST - 1) % NST);
+            mfmas(sl % NST);
+            if (sl + NST - 1 < NSL) deal();
+        }
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < NSL / NST; t++) {
+            const int sl = NST * t;
+#pragma unroll
+            for (int b = 0; b < NST; b++) {
+                const int nx = sl + b + NST - 1;
+                fetch(nx < NSL ? nx : NSL - 1, (b + NST - 1) % NST);
+                mfmas(b);
+                deal();
+            }
+        }
+        // the NSL % NST last slices sit in register sets 0 .. (their fetches were issued by the last trip of the loop)
+#pragma unroll
+        for (int b = 0; b < NSL % NST; b++) mfmas(b);
+    }
 }
 
 // power-of-two scale that brings a position's largest magnitude m into [2^13, 2^14), and its inverse (both exact).
@@ -233,7 +280,8 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     if (s0 >= n) return;
     // waves along cells / channels; 32-cell and 32-channel fragments per wave
     constexpr int NWB = NS == 2 ? 1 : 2, SNF = NS == 3 ? 2 : 3, NWA = NW / NWB, SMF = 4 / NWA;
-    constexpr int NST = NS == 3 ? 3 : 2;   // operand register sets (the 64 x 64 tile leaves room for a third)
+    constexpr int NST = 2;                 // operand register sets (a third, tried on the 64 x 64 tile, measured within noise)
+    constexpr bool UNR = NS == 3;          // slice loops unrolled (the product configuration)
     static_assert(NWA * NWB == NW && NWA * SMF == 4 && NWB * SNF * 32 >= SCELLS, "wave grid must tile 128 channels x the cells");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
     if (NS == 2 && desync > 0) {
@@ -333,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
-    conv_split<9, 1, false, SMF, SNF, NST, 1>(w.w_stem, hi, lo, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF, SNF, NST, 1, false>(w.w_stem, hi, SROWS * SRS, brow, lane, fbase, acc);
     STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
     STAMP(2);
@@ -354,14 +402,14 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     for (int blk = 0; blk < 3; blk++) {
         STAMP(4 + 8 * blk);
         zero(acc);
-        conv_split<9, 4, true, SMF, SNF, NST>(w.w3[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<9, 4, true, SMF, SNF, NST, 2, UNR>(w.w3[blk], hi, SROWS * SRS, brow, lane, fbase, acc);
         STAMP(5 + 8 * blk);       // 3x3 convolution
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
         STAMP(6 + 8 * blk);       // bias + SiLU
         to_image(1 + 2 * blk, acc);  // t
         STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
-        conv_split<1, 4, true, SMF, SNF, NST>(w.w1[blk], hi, lo, brow, lane, fbase, acc);
+        conv_split<1, 4, true, SMF, SNF, NST, 2, UNR>(w.w1[blk], hi, SROWS * SRS, brow, lane, fbase, acc);
         STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
