@@ -79,13 +79,33 @@ __device__ unsigned long long g_split_ts[4][64];
 // from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
 // 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
 // NKH: k-steps of 16 per slice that hold anything (the stem's 3 input planes sit in the first one)
+// The weights of a convolution's FIRST slice, requested by the caller before the barriers that publish the convolution's input
+// image: they do not depend on it, and a convolution that starts by asking for them waits a whole L2 round trip with an idle
+// matrix pipe (1-2 k cycles per convolution, seven convolutions).
+template <int SMF>
+struct WPre {
+    f16x8 h[2][SMF], l[2][SMF];
+};
+template <int SMF, int NKH>
+__device__ inline void w_prefetch(const f16x8* __restrict__ w, int nsl, int lane, int fbase, WPre<SMF>& p) {
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, nsl * 2 * SMFT * 2 * 1024, 0x00020000);
+    const int wvo = lane * 16 + fbase * 2048;
+#pragma unroll
+    for (int kh = 0; kh < NKH; kh++)
+#pragma unroll
+        for (int f = 0; f < SMF; f++) {
+            p.h[kh][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, (kh * SMFT + f) * 2048, 0));
+            p.l[kh][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, (kh * SMFT + f) * 2048 + 1024, 0));
+        }
+}
+
 // UNROLLED: every slice is its own copy of the code, so the tap offsets (LDS) and the slice offsets (weights) are immediates and
 // the loop carries no address arithmetic at all; the weights come through buffer loads (SGPR descriptor + lane offset VGPR +
 // scalar / immediate offset: no 64-bit vector adds).  LO_OFF: distance in halves from the hi plane to the lo plane.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int TAPS, int PER_TAP, bool LO_INPUT, int SMF, int SNF, int NST, int NKH = 2, bool UNROLLED = false>
 __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* hi, int lo_off, const int (&brow)[SNF],
-                                  int lane, int fbase, f32x16 (&acc)[SMF][SNF]) {
+                                  int lane, int fbase, f32x16 (&acc)[SMF][SNF], const WPre<SMF>& pre) {
     constexpr int NSL = TAPS * PER_TAP;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, NSL * 2 * SMFT * 2 * 1024, 0x00020000);
     const int wvo = lane * 16 + fbase * 2048;   // this lane's bytes inside a (slice, k-step) block of 4 fragments x hi | lo
@@ -94,11 +114,16 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     f16x8 ah[NST][2][SMF], al[NST][2][SMF], bh[NST][2][SNF], bl[NST][2][SNF];
     // operands of one slice into register set b: B from the image rows bb[j] (+ immediate k offset boff, in halves), A from the
     // weight block at byte offset wso (uniform) of the layer
-    auto fetch_at = [&](const int (&bb)[SNF], int boff, int wso, int b) {
+    auto fetch_at = [&](const int (&bb)[SNF], int boff, int wso, int b, bool a_from_pre = false) {
 #pragma unroll
         for (int kh = 0; kh < NKH; kh++) {
 #pragma unroll
             for (int f = 0; f < SMF; f++) {
+                if (a_from_pre) {   // slice 0: the caller asked for these before the barriers
+                    ah[b][kh][f] = pre.h[kh][f];
+                    al[b][kh][f] = pre.l[kh][f];
+                    continue;
+                }
 #ifdef AZ_K3S_DBG_NOW   // diagnostic builds only (tools/k3_variants.sh): no weight traffic, results are garbage
                 ah[b][kh][f] = (f16x8)((_Float16)(0.001f * (float)(wso + f)));
                 al[b][kh][f] = (f16x8)((_Float16)(0.002f * (float)(wso + kh)));
@@ -122,12 +147,12 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
         }
     };
     auto tap_off = [](int tap) { return ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS; };
-    auto fetch = [&](int sl, int b) {
+    auto fetch = [&](int sl, int b, bool a_from_pre = false) {
         const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
         int bb[SNF];
 #pragma unroll
         for (int j = 0; j < SNF; j++) bb[j] = brow[j] + tap_off(tap);
-        fetch_at(bb, cs * 32, sl * (2 * SMFT * 2048), b);
+        fetch_at(bb, cs * 32, sl * (2 * SMFT * 2048), b, a_from_pre);
     };
     auto mfmas = [&](int b) {  // product by product: 6 independent accumulators between two uses of the same one
 #pragma unroll
@@ -170,7 +195,7 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
     };
     static_assert(NSL >= NST, "fewer slices than operand register sets");
 #pragma unroll
-    for (int b = 0; b + 1 < NST; b++) fetch(b, b);
+    for (int b = 0; b + 1 < NST; b++) fetch(b, b, b == 0);
     if constexpr (UNROLLED && TAPS == 9 && PER_TAP == 4) {
         // one trip per tap, its four slices unrolled (two register sets): the image rows of this tap and of the next one are
         // kept as per-lane bases, so that a slice's operands are base + immediate; 2 SNF vector adds per tap, none per slice
@@ -284,6 +309,8 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     constexpr bool UNR = NS == 3;          // slice loops unrolled (the product configuration)
     static_assert(NWA * NWB == NW && NWA * SMF == 4 && NWB * SNF * 32 >= SCELLS, "wave grid must tile 128 channels x the cells");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+    WPre<SMF> pre;   // first-slice weights of the next convolution, requested ahead of the barriers (w_prefetch)
+    w_prefetch<SMF, 1>(w.w_stem, 9, lane, SMF * (wave % NWA), pre);   // the stem's, under the image set-up
     if (NS == 2 && desync > 0) {
         // Two workgroups share a CU and one wave of each shares every SIMD.  Started together they would walk the layers in
         // step and their epilogues would coincide; the workgroup whose waves sit in the odd wave slots starts `desync` x 8 k
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
-    conv_split<9, 1, false, SMF, SNF, NST, 1, false>(w.w_stem, hi, SROWS * SRS, brow, lane, fbase, acc);
+    conv_split<9, 1, false, SMF, SNF, NST, 1, false>(w.w_stem, hi, SROWS * SRS, brow, lane, fbase, acc, pre);
     STAMP(1);
     activate(acc, w.b_stem, w.inv_stem, nullptr);
     STAMP(2);
@@ -395,6 +422,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
             for (int j = 0; j < SNF; j++) xres[f][j] = a[f][j];
     };
     keep(acc);
+    w_prefetch<SMF, 2>(w.w3[0], 36, lane, fbase, pre);
     to_image(0, acc);
     STAMP(3);
 
@@ -402,18 +430,20 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     for (int blk = 0; blk < 3; blk++) {
         STAMP(4 + 8 * blk);
         zero(acc);
-        conv_split<9, 4, true, SMF, SNF, NST, 2, UNR>(w.w3[blk], hi, SROWS * SRS, brow, lane, fbase, acc);
+        conv_split<9, 4, true, SMF, SNF, NST, 2, UNR>(w.w3[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
         STAMP(5 + 8 * blk);       // 3x3 convolution
         activate(acc, w.b3[blk], w.inv3[blk], nullptr);
         STAMP(6 + 8 * blk);       // bias + SiLU
+        w_prefetch<SMF, 2>(w.w1[blk], 4, lane, fbase, pre);
         to_image(1 + 2 * blk, acc);  // t
         STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
-        conv_split<1, 4, true, SMF, SNF, NST, 2, UNR>(w.w1[blk], hi, SROWS * SRS, brow, lane, fbase, acc);
+        conv_split<1, 4, true, SMF, SNF, NST, 2, UNR>(w.w1[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
         STAMP(8 + 8 * blk);       // 1x1 convolution
         activate(acc, w.b1[blk], w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
         keep(acc);
+        if (blk < 2) w_prefetch<SMF, 2>(w.w3[blk + 1], 36, lane, fbase, pre);
         to_image(2 + 2 * blk, acc);
         STAMP(10 + 8 * blk);
     }
