@@ -367,8 +367,17 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
 #pragma unroll
                 for (int i = 0; i < 16; i++) a[f][j][i] = 0.f;
     };
+    // this lane's 16 SMF folded BatchNorm biases of a layer, requested BEFORE the layer's convolution so that the epilogue does
+    // not open with a round trip to L2
+    f32x4 bia[SMF][4];
+    auto load_bias = [&](const float* bias) {
+#pragma unroll
+        for (int f = 0; f < SMF; f++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) bia[f][q] = *reinterpret_cast<const f32x4*>(bias + ch0 + 32 * f + 8 * q);
+    };
     // a = SiLU(a * (inv / scale of the image the convolution read) + bias[channel] (+ res))
-    auto activate = [&](f32x16 (&a)[SMF][SNF], const float* bias, float inv, const f32x16 (*res)[SNF]) {
+    auto activate = [&](f32x16 (&a)[SMF][SNF], float inv, const f32x16 (*res)[SNF]) {
         float invj[SNF];
 #pragma unroll
         for (int j = 0; j < SNF; j++) invj[j] = inv * isc[j];
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         for (int f = 0; f < SMF; f++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ch0 + 32 * f + 8 * q);
+                const f32x4 bb = bia[f][q];
 #pragma unroll
                 for (int j = 0; j < SNF; j++)
 #pragma unroll
@@ -408,9 +417,10 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half
     STAMP(0);
     zero(acc);
+    load_bias(w.b_stem);
     conv_split<9, 1, false, SMF, SNF, NST, 1, false>(w.w_stem, hi, SROWS * SRS, brow, lane, fbase, acc, pre);
     STAMP(1);
-    activate(acc, w.b_stem, w.inv_stem, nullptr);
+    activate(acc, w.inv_stem, nullptr);
     STAMP(2);
     // this lane's own entries of x in fp32, kept for the residual while the image holds t (what the image holds is x rounded
     // to the 22 bits of a hi / lo pair; the residual takes the unrounded value)
@@ -430,17 +440,19 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     for (int blk = 0; blk < 3; blk++) {
         STAMP(4 + 8 * blk);
         zero(acc);
+        load_bias(w.b3[blk]);
         conv_split<9, 4, true, SMF, SNF, NST, 2, UNR>(w.w3[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
         STAMP(5 + 8 * blk);       // 3x3 convolution
-        activate(acc, w.b3[blk], w.inv3[blk], nullptr);
+        activate(acc, w.inv3[blk], nullptr);
         STAMP(6 + 8 * blk);       // bias + SiLU
         w_prefetch<SMF, 2>(w.w1[blk], 4, lane, fbase, pre);
         to_image(1 + 2 * blk, acc);  // t
         STAMP(7 + 8 * blk);       // range, split, store, two barriers
         zero(acc);
+        load_bias(w.b1[blk]);
         conv_split<1, 4, true, SMF, SNF, NST, 2, UNR>(w.w1[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
         STAMP(8 + 8 * blk);       // 1x1 convolution
-        activate(acc, w.b1[blk], w.inv1[blk], xres);
+        activate(acc, w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
         keep(acc);
         if (blk < 2) w_prefetch<SMF, 2>(w.w3[blk + 1], 36, lane, fbase, pre);
