@@ -148,6 +148,76 @@ __device__ inline typename G::State opening_state(const Dev& d, u64 gid) {
     return s;
 }
 
+// ---- wave-aggregated reservations on a global counter.  Whole cohorts of games end on the same ply (4 096 TicTacToe games, all
+// 5 to 9 plies long): with one compare-and-swap loop per lane those lanes serialise on one address (8.7 ms for a ply end that
+// takes 26 us otherwise); here the lanes of a wave that arrive together add up their needs and ONE lane runs the loop.
+
+// Every calling lane reserves n units of *ctr without ever moving it past `limit`.  Returns the lane's first unit, or ~0 when
+// its n units do not fit (the counter is then untouched by this lane).
+__device__ inline unsigned long long wave_reserve(unsigned long long* ctr, u32 n, unsigned long long limit) {
+    const u64 m = __ballot(1);
+    const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+    unsigned long long pre = 0, tot = 0;
+    for (u64 mm = m; mm; mm &= mm - 1) {
+        const int src = __ffsll((long long)mm) - 1;
+        const u32 v = (u32)__shfl((int)n, src);
+        if (src < lane) pre += v;
+        tot += v;
+    }
+    u32 lo = ~0u, hi = ~0u;
+    if (lane == leader) {
+        unsigned long long off = atomicAdd(ctr, 0ull);
+        while (off + tot <= limit) {
+            const unsigned long long prev = atomicCAS(ctr, off, off + tot);
+            if (prev == off) {
+                lo = (u32)off;
+                hi = (u32)(off >> 32);
+                break;
+            }
+            off = prev;
+        }
+    }
+    lo = (u32)__shfl((int)lo, leader);
+    hi = (u32)__shfl((int)hi, leader);
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+    if (base != ~0ull) return base + pre;
+    // the wave's units do not all fit any more: lane by lane, so that the ones that still fit are not lost
+    unsigned long long off = atomicAdd(ctr, 0ull);
+    while (off + n <= limit) {
+        const unsigned long long prev = atomicCAS(ctr, off, off + (unsigned long long)n);
+        if (prev == off) return off;
+        off = prev;
+    }
+    return ~0ull;
+}
+
+// Every calling lane takes one index below `target` from *ctr, in lane order; ~0 for the lanes that find the target reached.
+__device__ inline unsigned long long wave_take_one(unsigned long long* ctr, unsigned long long target) {
+    const u64 m = __ballot(1);
+    const int lane = (int)__lane_id(), leader = __ffsll((long long)m) - 1;
+    const u32 cnt = (u32)__popcll(m), rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
+    u32 lo = 0, hi = 0, grant = 0;
+    if (lane == leader) {
+        unsigned long long idx = atomicAdd(ctr, 0ull);
+        while (idx < target) {
+            const unsigned long long g = target - idx < cnt ? target - idx : (unsigned long long)cnt;
+            const unsigned long long prev = atomicCAS(ctr, idx, idx + g);
+            if (prev == idx) {
+                grant = (u32)g;
+                lo = (u32)idx;
+                hi = (u32)(idx >> 32);
+                break;
+            }
+            idx = prev;
+        }
+    }
+    lo = (u32)__shfl((int)lo, leader);
+    hi = (u32)__shfl((int)hi, leader);
+    grant = (u32)__shfl((int)grant, leader);
+    if (rank >= grant) return ~0ull;
+    return (((unsigned long long)hi << 32) | lo) + rank;
+}
+
 // env.step(a) + prune_root(a)/reset_player() + trajectory bookkeeping for the active game g (a >= 0).
 template <class G>
 __device__ inline void advance_game(const Dev& d, const Play& p, int g, int a, const float* pi, i64 pi_stride, int reuse,
@@ -193,18 +263,10 @@ __device__ inline void advance_game(const Dev& d, const Play& p, int g, int a, c
         atomicAdd(&d.stats[ST_GAMES], 1ull);
         if (record) {  // game.py:50-58: commit the finished game with z from each mover's perspective
             int n = ply < G::MAX_PLIES ? ply : G::MAX_PLIES;
-            // reserve n rows with a compare-and-swap loop: out_count only ever covers rows that get written, so a game
-            // that does not fit is dropped without leaving a hole and later, shorter games may still fit
-            unsigned long long off = atomicAdd(p.out_count, 0ull);
-            bool fits = false;
-            while ((i64)off + n <= p.out_cap) {
-                const unsigned long long prev = atomicCAS(p.out_count, off, off + (unsigned long long)n);
-                if (prev == off) {
-                    fits = true;
-                    break;
-                }
-                off = prev;
-            }
+            // reserve n rows below out_cap: out_count only ever covers rows that get written, so a game that does not fit is
+            // dropped without leaving a hole and later, shorter games may still fit
+            const unsigned long long off = wave_reserve(p.out_count, (u32)n, (unsigned long long)p.out_cap);
+            const bool fits = off != ~0ull;
             if (fits) {
                 for (int j = 0; j < n; j++) {
                     i64 o = (i64)g * G::MAX_PLIES + j, q = (i64)off + j;
@@ -229,15 +291,10 @@ __device__ inline void advance_game(const Dev& d, const Play& p, int g, int a, c
 template <class G>
 __device__ inline void refill_game(const Dev& d, const Play& p, int g, unsigned long long target, u64 gid_base) {
     if (d.active[g] || !d.done[g]) return;
-    // take the next game index while it is below the target (compare-and-swap: the counter never runs past the target,
-    // so the target may be raised between launches and exactly `target` games are ever started)
-    unsigned long long idx = atomicAdd(p.games_started, 0ull);
-    for (;;) {
-        if (idx >= target) return;
-        const unsigned long long prev = atomicCAS(p.games_started, idx, idx + 1ull);
-        if (prev == idx) break;
-        idx = prev;
-    }
+    // take the next game index while it is below the target (the counter never runs past the target, so the target may be
+    // raised between launches and exactly `target` games are ever started)
+    const unsigned long long idx = wave_take_one(p.games_started, target);
+    if (idx == ~0ull) return;
     u64 gid = gid_base + d.gid_stride * idx;
     typename G::State s = opening_state<G>(d, gid);
     for (int i = 0; i < G::W; i++) d.root_state[(i64)g * G::W + i] = s.w[i];

@@ -844,15 +844,16 @@ __global__ __launch_bounds__(256) void k_puct(i64 n, const i32* Np, const i32* n
 
 static inline int game_of(const Dev& d) { return d.game; }
 
-// games per wave of the fused searches.  Measured (tools/bench_configs.py; TicTacToe 4 096 x 100 / NBTTT 8 192 x 800, kernel time
-// per launch): 4 games per wave 0.45 / 10.3 ms, 2: 0.46 / 11.0, 1: 0.54 / 19.8 -- a launch lasts as long as ONE game's chain
-// of playouts, which more waves do not shorten, while lanes left idle cost issue slots.  So every lane is used;
-// AZ_TREE_GPW overrides (measurement hook).
+// games per wave of the fused searches (a game is touched only by its own lane group, so results do not depend on it);
+// AZ_TREE_GPW overrides the default (measurement hook).
 template <class GT>
 static int pick_gpw(const Dev&) {
     constexpr int full = 64 / GT::LG;
     static const char* env = getenv("AZ_TREE_GPW");
-    int gpw = env ? atoi(env) : full;
+    // default: half-filled waves.  A wave lasts as long as its slowest game, and with fewer games per wave less of it idles
+    // behind the deepest walk / longest rollout (measured, full -> half -> quarter: NBTTT 8 192 x 800 7.24 / 6.31 / 10.7 ms,
+    // pure MCTS 4 096 x 1 000 26.2 / 22.9 / 22.8 ms, TicTacToe 4 096 x 100 0.428 / 0.433 / 0.519 ms)
+    int gpw = env ? atoi(env) : full / 2;
     if (gpw < 1) gpw = 1;
     if (gpw > full) gpw = full;
     return gpw;
