@@ -6,8 +6,10 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on, per GPU): Connect4 self-play,
 2048 concurrent games, 500 playouts per move, the reference's real CNN checkpoint evaluated on whole leaf batches
-by the fused fp32-MFMA kernel (Winograd form), Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for
-10 plies then 1e-3, tree reuse, finished slots refilled with fresh games (Connect4/config.py:1-14).
+by the fused K3 kernel (product form: fp32 products as three fp16 MFMA products on split operands, fp32 accumulation,
+az_cnn_split.hip; --k3 wino: Winograd on fp32 MFMA; the other form is measured as a second leg of the same line),
+Dirichlet alpha 0.7 at every expansion, random mirror augmentation, temperature 1.0 for 10 plies then 1e-3, tree reuse,
+finished slots refilled with fresh games (Connect4/config.py:1-14).
 A "step" = 500 rounds of every game slot, a round = CNN on the parked leaf batch -> tree step (expand/backup, and for
 the games whose move is complete: move selection, env step, trajectory record, refill; then the walk to the next leaf).
 In the default rolling mode (az_selfplay_rounds) the games advance individually and every round evaluates one
@@ -52,9 +54,11 @@ EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi)
-# HBM bytes per launch of the split kernel (PMC pass, profiles/r01_k3_split.txt: 17.4 MB = its 3.8 MB of split weights per XCD L2)
-K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = 17.4e6
-K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC pass, profiles/r01_k3_split.txt"
+# HBM bytes per launch of the split kernel in THIS workload (PMC passes on bench.py itself, profiles/r02_k3_pmc.txt:
+# FETCH_SIZE 8271.7 KB x 2 + WRITE_SIZE 18.1 KB): the 2.0 MB of split weights once per XCD L2 per launch; positions in
+# and outputs out are ~25 KB of it
+K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8271.7 + 18.1) * 1024
+K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r02_k3_pmc.txt"
 DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 

@@ -3,16 +3,17 @@
 // only pays if this is true.)  512-thread workgroup = two waves per SIMD; waves 0-3 run NM x 8 MFMAs (32x32x16 f16, 8
 // independent accumulators), waves 4-7 run NV x 8 blocks of VALU work.  kind 0: {v_exp, v_rcp, 3 mul/fma} (SiLU-like),
 // kind 1: 6 plain fma.  Modes: 1 MFMA waves only, 2 VALU waves only, 3 both.  Times in shader cycles (s_memtime) of wave 0 / 4
-// and in microseconds for the launch, one workgroup per CU on every CU.  prio 1: the arithmetic waves run at s_setprio 3.
-// Result (MI355X): at equal priority the arithmetic wave gets NO issue slot while its SIMD partner streams MFMAs back to back
-// (both = sum); at s_setprio 3 it runs under them (both = max).
+// and in microseconds for the launch, one workgroup per CU on every CU.  prio 0: equal priority; prio 1: the arithmetic waves
+// run at s_setprio 3; prio 2 / 3 / 4: the MFMA wave idles on the scalar side (s_nop / s_sleep) after every MFMA.
+// Result (MI355X): see profiles/r02_k3_split_breakdown.txt and DESIGN.md 4.2.
 // build: hipcc --offload-arch=gfx950 -O3 -o dbgbuild/coexec tools/ubench/coexec.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc, int nm, int nv, int mode, int kind, int prio) {
+template <int prio>   // a template parameter: a run-time test between two MFMAs would itself open issue gaps
+__global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc, int nm, int nv, int mode, int kind) {
     const int wave = threadIdx.x >> 6;
     float s = 0.f;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -87,7 +88,13 @@ int main() {
                 if (prio >= 2 && (kind != 0 || nv != 2048)) continue;   // the idling variants: one line each
                 for (int rep = 0; rep < 2; rep++) {
                     (void)hipEventRecord(e0);
-                    k<<<256, 512>>>(out, cyc, nm, nv, mode, kind, prio);
+                    switch (prio) {
+                    case 0: k<0><<<256, 512>>>(out, cyc, nm, nv, mode, kind); break;
+                    case 1: k<1><<<256, 512>>>(out, cyc, nm, nv, mode, kind); break;
+                    case 2: k<2><<<256, 512>>>(out, cyc, nm, nv, mode, kind); break;
+                    case 3: k<3><<<256, 512>>>(out, cyc, nm, nv, mode, kind); break;
+                    default: k<4><<<256, 512>>>(out, cyc, nm, nv, mode, kind); break;
+                    }
                     (void)hipEventRecord(e1);
                     (void)hipEventSynchronize(e1);
                 }
