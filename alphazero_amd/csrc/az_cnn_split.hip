@@ -60,14 +60,27 @@ struct CnnS {
 
 __host__ __device__ inline int scell(int s, int r, int c) { return SFRONT + s * 63 + (r + 1) * 9 + (c + 1); }
 __device__ inline float ssilu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// sum over the 64 lanes, the same value in every lane: four DPP steps inside a row of 16 (quad swaps, then the half-row
+// and row mirrors, which pair up groups whose lanes already agree), then the four rows through the scalar side
+template <int CTRL>
+__device__ inline float sdpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ inline float swave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = sdpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = sdpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = sdpp_add<0x141>(v);   // row_half_mirror
+    v = sdpp_add<0x140>(v);   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 #ifdef AZ_K3S_DBG_TS   // diagnostic builds only (tools/k3_variants.sh, tools/k3s_stamps.py): shader-clock stamps of one wave
 __device__ unsigned long long g_split_ts[4][64];
-#define STAMP(i) do { if (blockIdx.x == 7 && lane == 0) g_split_ts[wave & 3][i] = __builtin_readcyclecounter(); } while (0)
+#ifndef AZ_K3S_TS_BLOCK
+#define AZ_K3S_TS_BLOCK 7
+#endif
+#define STAMP(i) do { if (blockIdx.x == AZ_K3S_TS_BLOCK && lane == 0) g_split_ts[wave & 3][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -291,7 +304,8 @@ template <int NS, int NW>
 __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
                                                               const u32* __restrict__ list, const u64* __restrict__ states,
                                                               float* __restrict__ logp, float* __restrict__ logv,
-                                                              float* __restrict__ probs, float* __restrict__ value, int desync) {
+                                                              float* __restrict__ probs, float* __restrict__ value, int desync,
+                                                              u32 max_n) {
     extern __shared__ _Float16 lds[];
     constexpr int SNS = NS, SCELLS = NS * 42, SROWS = srows(NS);
     __shared__ float hb[4][SCELLS];  // head activations: 3 policy channels, 1 value channel
@@ -300,17 +314,24 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     __shared__ u32 s_amax[7][SNS];   // per layer output and position: bits of the largest |activation| (ds_max_u32)
     _Float16* hi = lds;
     _Float16* lo = lds + SROWS * SRS;
-    const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
     const i64 s0 = (i64)blockIdx.x * SNS;
-    if (s0 >= n) return;
     // waves along cells / channels; 32-cell and 32-channel fragments per wave
     constexpr int NWB = NS == 2 ? 1 : 2, SNF = NS == 3 ? 2 : 3, NWA = NW / NWB, SMF = 4 / NWA;
     constexpr int NST = 2;                 // operand register sets (a third, tried on the 64 x 64 tile, measured within noise)
     constexpr bool UNR = NS == 3;          // slice loops unrolled (the product configuration)
     static_assert(NWA * NWB == NW && NWA * SMF == 4 && NWB * SNF * 32 >= SCELLS, "wave grid must tile 128 channels x the cells");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+    STAMP(30);   // kernel entry
+    // ---- set-up.  Three dependent global reads stand between a workgroup and its first MFMA (leaf count -> leaf list -> position);
+    // the count and the list entry are requested together (the list holds max_n entries whatever the count says), the image is
+    // cleared while they travel, and the position's words are requested before the second half of the clearing.
     WPre<SMF> pre;   // first-slice weights of the next convolution, requested ahead of the barriers (w_prefetch)
     w_prefetch<SMF, 1>(w.w_stem, 9, lane, SMF * (wave % NWA), pre);   // the stem's, under the image set-up
+    const int ps = tid / 42, pq = tid % 42;                   // thread -> (position, cell) of the input planes, tid < SCELLS
+    const bool mine = tid < SCELLS;
+    u32 li = 0u;
+    if (list && mine && s0 + ps < (i64)max_n) li = list[s0 + ps];
+    const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
     if (NS == 2 && desync > 0) {
         // Two workgroups share a CU and one wave of each shares every SIMD.  Started together they would walk the layers in
         // step and their epilogues would coincide; the workgroup whose waves sit in the odd wave slots starts `desync` x 8 k
@@ -319,25 +340,33 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         if (slot)
             for (int i = 0; i < desync; i++) __builtin_amdgcn_s_sleep(127);
     }
-    for (int i = tid; i < SROWS * SRS; i += NW * 64) reinterpret_cast<unsigned*>(lds)[i] = 0u;
+    constexpr int NZ = SROWS * SRS / 4;    // the image (both planes) in 16-byte units
+    static_assert(SROWS * SRS % 4 == 0, "image size in 16-byte units");
+    u32x4* const lds16 = reinterpret_cast<u32x4*>(lds);
+    for (int i = tid; i < NZ / 2; i += NW * 64) lds16[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (s0 >= n) return;
+    const bool have = mine && s0 + ps < n;
+    const i64 myslot = list ? (i64)li : (s0 + ps);
+    u64 w0 = 0, w1 = 0;
+    if (have) {
+        w0 = states[myslot * 2];
+        w1 = states[myslot * 2 + 1];
+    }
+    for (int i = NZ / 2 + tid; i < NZ; i += NW * 64) lds16[i] = (u32x4){0u, 0u, 0u, 0u};
     if (tid < 7 * SNS) (&s_amax[0][0])[tid] = 0u;
     __syncthreads();
     // ---- input planes from bitboards (env.current_state, env_cython.pyx:143-149): channels 0..2, exact in fp16
-    if (tid < SCELLS) {
-        const int s = tid / 42, q = tid % 42, row = q / 7, col = q % 7;
-        if (s0 + s < n) {
-            const i64 slot = list ? (i64)list[s0 + s] : (s0 + s);
-            const u64 w0 = states[slot * 2], w1 = states[slot * 2 + 1];
-            const int bit = col * 7 + (5 - row);
-            const float vt = (w1 >> 63) ? -1.f : 1.f;
-            _Float16* p = hi + scell(s, row, col) * SRS;
-            p[0] = (_Float16)(float)((w0 >> bit) & 1ull);
-            p[1] = (_Float16)(float)((w1 >> bit) & 1ull);
-            p[2] = (_Float16)vt;
-            if (q == 0) {
-                s_player[s] = vt;
-                s_slot[s] = slot;
-            }
+    if (have) {
+        const int row = pq / 7, col = pq % 7;
+        const int bit = col * 7 + (5 - row);
+        const float vt = (w1 >> 63) ? -1.f : 1.f;
+        _Float16* p = hi + scell(ps, row, col) * SRS;
+        p[0] = (_Float16)(float)((w0 >> bit) & 1ull);
+        p[1] = (_Float16)(float)((w1 >> bit) & 1ull);
+        p[2] = (_Float16)vt;
+        if (pq == 0) {
+            s_player[ps] = vt;
+            s_slot[ps] = myslot;
         }
     }
     __syncthreads();
@@ -455,17 +484,46 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         activate(acc, w.inv1[blk], xres);
         STAMP(9 + 8 * blk);
         keep(acc);
-        if (blk < 2) w_prefetch<SMF, 2>(w.w3[blk + 1], 36, lane, fbase, pre);
+        if (blk < 2) {
+            w_prefetch<SMF, 2>(w.w3[blk + 1], 36, lane, fbase, pre);
+        } else if constexpr (SMF == 2) {
+            // the heads' convolution weights (8 fragments per lane) travel in the registers of the first-slice weights
+#pragma unroll
+            for (int cs = 0; cs < 4; cs++) {
+                pre.h[cs >> 1][cs & 1] = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane];
+                pre.l[cs >> 1][cs & 1] = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
+            }
+        }
         to_image(2 + 2 * blk, acc);
         STAMP(10 + 8 * blk);
     }
+    // what the end of the network reads from memory, requested before the heads' MFMAs: the heads' biases, and for the waves that
+    // finish a position (wave s, position s) that position's share of the Linear weights -- lane j holds the weights of the
+    // flattened inputs j and j + 64 (nn.Flatten of NCHW: c*42 + h*7 + w)
+    float pw[2][7], vw[3], hbias[4], pbias[7], vbias[3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) hbias[r] = w.b_head[r];
+#pragma unroll
+    for (int a = 0; a < 7; a++) pbias[a] = w.plin_b[a];
+#pragma unroll
+    for (int k = 0; k < 3; k++) vbias[k] = w.vlin_b[k];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 7; a++) pw[i][a] = (wave < SNS && lane + 64 * i < 126) ? w.plin_w[a * 126 + lane + 64 * i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) vw[k] = (wave < SNS && lane < 42) ? w.vlin_w[k * 42 + lane] : 0.f;
 
     STAMP(28);
     // ---- heads: conv1x1(128->3) / conv1x1(128->1) + BN + SiLU (Network.py:38-51) as one 16-row fragment of
-    // v_mfma_f32_16x16x32_f16 (cell = lane % 16, k group = lane / 16); the waves with wa == 0 do it for their 96 cells
-    if (wa == 0) {
+    // v_mfma_f32_16x16x32_f16 (cell = lane % 16, k group = lane / 16); the 2 SNF groups of 16 cells of a wave column are
+    // dealt to the NWA waves of that column (all to the first one where they do not divide)
+    constexpr bool HSHARE = (2 * SNF) % NWA == 0;
+    constexpr int HJ = HSHARE ? 2 * SNF / NWA : 2 * SNF;
+    if (HSHARE || wa == 0) {
 #pragma unroll
-        for (int jj = 0; jj < 2 * SNF; jj++) {
+        for (int j0 = 0; j0 < HJ; j0++) {
+            const int jj = HSHARE ? wa * HJ + j0 : j0;
             int col = wb * (32 * SNF) + jj * 16 + n16;
             const bool lv = col < SCELLS;
             if (!lv) col = 0;
@@ -474,9 +532,16 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
             f32x4 a4 = (f32x4){0, 0, 0, 0};
 #pragma unroll
             for (int cs = 0; cs < 4; cs++) {
-                const f16x8 wh = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane], wl = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(hi + b16 + cs * 32);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(lo + b16 + cs * 32);
+                f16x8 wh, wl;
+                if constexpr (SMF == 2) {
+                    wh = pre.h[cs >> 1][cs & 1];
+                    wl = pre.l[cs >> 1][cs & 1];
+                } else {
+                    wh = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane];
+                    wl = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
+                }
                 SMFMA16(wh, bh, a4);
                 SMFMA16(wh, bl, a4);
                 SMFMA16(wl, bh, a4);
@@ -485,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
                 float hsc, hisc;   // the image holds the last block's output at its position's scale
                 range_scale(__uint_as_float(s_amax[6][sp]), hsc, hisc);
 #pragma unroll
-                for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * (w.inv_head * hisc) + w.b_head[r]);
+                for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * (w.inv_head * hisc) + hbias[r]);
             }
         }
     }
@@ -495,51 +560,44 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     const int s = wave;
     if (s >= SNS || s0 + s >= n) return;
     float pl[7], vl[3];
+    {
+        const float x0 = hb[lane / 42][s * 42 + lane % 42];                                   // flattened input j = lane
+        const float x1 = lane + 64 < 126 ? hb[(lane + 64) / 42][s * 42 + (lane + 64) % 42] : 0.f;
+        const float xv = lane < 42 ? hb[3][s * 42 + lane] : 0.f;
 #pragma unroll
-    for (int a = 0; a < 7; a++) pl[a] = 0.f;
+        for (int a = 0; a < 7; a++) pl[a] = swave_sum(x0 * pw[0][a] + x1 * pw[1][a]) + pbias[a];
 #pragma unroll
-    for (int k = 0; k < 3; k++) vl[k] = 0.f;
-    for (int j = lane; j < 126; j += 64) {  // nn.Flatten of NCHW: index c*42 + h*7 + w
-        const float xv = hb[j / 42][s * 42 + j % 42];
-#pragma unroll
-        for (int a = 0; a < 7; a++) pl[a] += xv * w.plin_w[a * 126 + j];
+        for (int k = 0; k < 3; k++) vl[k] = swave_sum(xv * vw[k]) + vbias[k];
     }
-    if (lane < 42) {
-        const float xv = hb[3][s * 42 + lane];
+    // every lane holds the 7 + 3 sums; the exponentials inside the log-sum-exps are the hardware's (their rounding enters the
+    // log-probabilities at 1e-7), the logarithms are libm's; lane a < 7 finishes action a, lanes 8..10 the value classes
+    float mx = pl[0];
 #pragma unroll
-        for (int k = 0; k < 3; k++) vl[k] += xv * w.vlin_w[k * 42 + lane];
-    }
+    for (int a = 1; a < 7; a++) mx = fmaxf(mx, pl[a]);
+    float se = 0.f;
 #pragma unroll
-    for (int a = 0; a < 7; a++) pl[a] = swave_sum(pl[a]) + w.plin_b[a];
+    for (int a = 0; a < 7; a++) se += __expf(pl[a] - mx);
+    const float lse = logf(se);
+    const float mv = fmaxf(vl[0], fmaxf(vl[1], vl[2]));
+    const float lsv = logf(__expf(vl[0] - mv) + __expf(vl[1] - mv) + __expf(vl[2] - mv));
+    const i64 slot = s_slot[s];
+    if (lane < 7) {
+        float mine_l = pl[0];
 #pragma unroll
-    for (int k = 0; k < 3; k++) vl[k] = swave_sum(vl[k]) + w.vlin_b[k];
-    if (lane == 0) {
-        const i64 slot = s_slot[s];
-        float mx = pl[0];
-#pragma unroll
-        for (int a = 1; a < 7; a++) mx = fmaxf(mx, pl[a]);
-        float se = 0.f;
-#pragma unroll
-        for (int a = 0; a < 7; a++) se += expf(pl[a] - mx);
-        const float lse = logf(se);
-        const float mv = fmaxf(vl[0], fmaxf(vl[1], vl[2]));
-        const float lsv = logf(expf(vl[0] - mv) + expf(vl[1] - mv) + expf(vl[2] - mv));
-        float vp[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float lv = vl[k] - mv - lsv;
-            if (logv) logv[slot * 3 + k] = lv;
-            vp[k] = expf(lv);
-        }
-#pragma unroll
-        for (int a = 0; a < 7; a++) {
-            const float lp = pl[a] - mx - lse;
-            if (logp) logp[slot * 7 + a] = lp;
-            if (probs) probs[slot * 7 + a] = expf(lp);
-        }
+        for (int a = 1; a < 7; a++) mine_l = lane == a ? pl[a] : mine_l;
+        const float lp = mine_l - mx - lse;
+        if (logp) logp[slot * 7 + lane] = lp;
+        if (probs) probs[slot * 7 + lane] = __expf(lp);
+    } else if (lane >= 8 && lane < 11) {
+        const int k = lane - 8;
+        const float lv = (k == 0 ? vl[0] : (k == 1 ? vl[1] : vl[2])) - mv - lsv;
+        if (logv) logv[slot * 3 + k] = lv;
+    } else if (lane == 16) {
         // Network.py:83-84: classes [draw, mover wins, mover loses]
-        if (value) value[slot] = (-s_player[s]) * 0.5f * vp[0] + vp[1] - vp[2];
+        const float v0 = __expf(vl[0] - mv - lsv), v1 = __expf(vl[1] - mv - lsv), v2 = __expf(vl[2] - mv - lsv);
+        if (value) value[slot] = (-s_player[s]) * 0.5f * v0 + v1 - v2;
     }
+    STAMP(31);   // this wave's end
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -682,13 +740,13 @@ int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32
     static const char* dsy = getenv("AZ_K3_SPLIT_DESYNC");
     const int desync = dsy ? atoi(dsy) : 0;
     if (kc == 48)
-        k_cnn_forward_split<4, 8><<<dim3((max_n + 3) / 4), dim3(512), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+        k_cnn_forward_split<4, 8><<<dim3((max_n + 3) / 4), dim3(512), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
     else if (kc == 34)
-        k_cnn_forward_split<3, 4><<<dim3((max_n + 2) / 3), dim3(256), split_lds(3), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+        k_cnn_forward_split<3, 4><<<dim3((max_n + 2) / 3), dim3(256), split_lds(3), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
     else if (kc == 24)
-        k_cnn_forward_split<2, 4><<<dim3((max_n + 1) / 2), dim3(256), split_lds(2), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+        k_cnn_forward_split<2, 4><<<dim3((max_n + 1) / 2), dim3(256), split_lds(2), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
     else
-        k_cnn_forward_split<4, 4><<<dim3((max_n + 3) / 4), dim3(256), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync);
+        k_cnn_forward_split<4, 4><<<dim3((max_n + 3) / 4), dim3(256), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }

@@ -51,6 +51,9 @@ def main():
         tot[key] = tot.get(key, 0) + int(d[0])
         prev = i
     print("total %d cycles (wave 0)" % (t[0, 29] - t[0, 0]))
+    print("entry -> first stamp (LDS image cleared, input planes): %s" % "  ".join("%8d" % x for x in t[:, 0] - t[:, 30]))
+    print("heads -> end (Linear, log-softmax, outputs; waves 0..2): %s" % "  ".join("%8d" % x for x in t[:, 31] - t[:, 29]))
+    print("entry -> end: %s" % "  ".join("%8d" % x for x in t[:, 31] - t[:, 30]))
     for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print("  %-20s %8d  %5.1f %%" % (k, v, 100.0 * v / (t[0, 29] - t[0, 0])))
     eng.close()
