@@ -28,6 +28,7 @@
 
 namespace az {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -407,9 +408,12 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     };
     // a = SiLU(a * (inv / scale of the image the convolution read) + bias[channel] (+ res))
     auto activate = [&](f32x16 (&a)[SMF][SNF], float inv, const f32x16 (*res)[SNF]) {
-        float invj[SNF];
+        // two values at a time on the packed fp32 instructions (v_pk_fma / v_pk_mul / v_pk_add: two values for the issue slot
+        // of one); per pair: fma, [add residual], mul by -log2 e, 2 x v_exp, add 1, 2 x v_rcp, mul
+        f32x2 invj[SNF];
 #pragma unroll
-        for (int j = 0; j < SNF; j++) invj[j] = inv * isc[j];
+        for (int j = 0; j < SNF; j++) invj[j] = (f32x2){inv * isc[j], inv * isc[j]};
+        const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
 #pragma unroll
         for (int f = 0; f < SMF; f++)
 #pragma unroll
@@ -418,10 +422,15 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
 #pragma unroll
                 for (int j = 0; j < SNF; j++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float v = a[f][j][4 * q + r] * invj[j] + bb[r];
-                        if (res) v += res[f][j][4 * q + r];
-                        a[f][j][4 * q + r] = ssilu(v);
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 a2 = {a[f][j][4 * q + r], a[f][j][4 * q + r + 1]};
+                        f32x2 v = a2 * invj[j] + (f32x2){bb[r], bb[r + 1]};
+                        if (res) v += (f32x2){res[f][j][4 * q + r], res[f][j][4 * q + r + 1]};
+                        const f32x2 t = v * nl2e;
+                        const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + one;
+                        const f32x2 o = v * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                        a[f][j][4 * q + r] = o[0];
+                        a[f][j][4 * q + r + 1] = o[1];
                     }
             }
     };
@@ -437,10 +446,13 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
                 for (int i = 0; i < 16; i++) m = fmaxf(m, fabsf(a[f][j][i]));
             if (live[j]) atomicMax(&s_amax[layer][cpos[j]], __float_as_uint(m));
         }
+        if (layer == 3) STAMP(32);
         __syncthreads();
+        if (layer == 3) STAMP(33);
 #pragma unroll
         for (int j = 0; j < SNF; j++) range_scale(__uint_as_float(s_amax[layer][cpos[j]]), sc[j], isc[j]);
         store_image<SMF, SNF>(hi, lo, crow, live, ch0, a, sc);
+        if (layer == 3) STAMP(34);
         __syncthreads();
     };
     // ---- stem: conv3x3(3->128) + BN + SiLU (Network.py:33-36); the input has no lo half

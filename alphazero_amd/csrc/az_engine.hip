@@ -533,7 +533,7 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     hipError_t he = hipStreamCreate(&e->stream);
     // cohorts only pay off where an evaluator launch sits between select and backup (AZ_EVAL_CNN)
     int C = cfg->n_cohorts;
-    if (C <= 0) C = cfg->evaluator != AZ_EVAL_CNN ? 1 : (G >= 2048 ? 4 : G >= 768 ? 3 : (G >= 512 ? 2 : 1));  // measured: DESIGN.md 5
+    if (C <= 0) C = cfg->evaluator != AZ_EVAL_CNN ? 1 : (G >= 4096 ? 4 : G >= 768 ? 3 : (G >= 512 ? 2 : 1));  // measured: DESIGN.md 5
     if (C > AZ_MAX_COHORTS) C = AZ_MAX_COHORTS;
     if (cfg->evaluator != AZ_EVAL_CNN || C > G) C = 1;
     e->C = C;

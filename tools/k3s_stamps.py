@@ -53,6 +53,10 @@ def main():
     print("total %d cycles (wave 0)" % (t[0, 29] - t[0, 0]))
     print("entry -> first stamp (LDS image cleared, input planes): %s" % "  ".join("%8d" % x for x in t[:, 0] - t[:, 30]))
     print("heads -> end (Linear, log-softmax, outputs; waves 0..2): %s" % "  ".join("%8d" % x for x in t[:, 31] - t[:, 29]))
+    if t[0, 32] > 0:   # inside the epilogue of blk1's t (layer 3): SiLU + maximum | barrier | scale, split, store | barrier
+        for a, b, name in ((14, 32, "conv3x3 end -> maxima published"), (32, 33, "barrier 1"), (33, 34, "scale, split, store"),
+                           (34, 15, "barrier 2")):
+            print("blk1 t: %-32s %s" % (name, "  ".join("%8d" % x for x in t[:, b] - t[:, a])))
     print("entry -> end: %s" % "  ".join("%8d" % x for x in t[:, 31] - t[:, 30]))
     for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print("  %-20s %8d  %5.1f %%" % (k, v, 100.0 * v / (t[0, 29] - t[0, 0])))
