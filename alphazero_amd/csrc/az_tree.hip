@@ -553,7 +553,15 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
 // tree-step workgroup waits for a CU to come free: fewer, larger workgroups (512 threads = 64 Connect4 games) need
 // fewer CUs and start sooner.
 template <class G, int BS>
-__global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
+// (Measured, round 2: a 256-thread tree step capped at 128 registers per lane -- AZ_TREE_STEP_VGPR=128, AZ_TREE_STEP_BS=256 --
+// fits on a CU beside a K3 workgroup and starts at once, 8 us instead of 68; the bench LOSES 3.5 % with it, 866 against 897
+// games/s on one box: the GPU is bound by K3 workgroup time, and a tree step sharing a CU's issue ports slows that K3 workgroup.)
+#ifdef AZ_TREE_STEP_VGPR
+#define AZ_TREE_STEP_ATTR __attribute__((amdgpu_waves_per_eu(512 / AZ_TREE_STEP_VGPR, 8)))
+#else
+#define AZ_TREE_STEP_ATTR
+#endif
+__global__ __launch_bounds__(BS) AZ_TREE_STEP_ATTR void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
     constexpr int LG = G::LG, GPB = BS / LG;
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
