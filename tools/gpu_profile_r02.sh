@@ -30,6 +30,7 @@ if [ $PART = k3 ] || [ $PART = all ]; then
   AZAMD_LIB=dbgbuild/libazamd_AZ_K3S_DBG_TS.so timeout -k 10 100 python3 tools/k3s_stamps.py 6144 > $O/k3_stamps.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/coexec > $O/coexec.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/fillers > $O/fillers.log 2>&1 || exit 1
+  timeout -k 5 60 ./dbgbuild/valu_rate > $O/valu_rate.log 2>&1 || exit 1
 fi
 if [ $PART = tree ] || [ $PART = all ]; then
   T="python3 tools/bench_configs.py k1 ttt nbttt pure unpack"

@@ -113,6 +113,8 @@ def k3():
         f.write(logtext("coexec.log"))
         f.write("## tools/ubench/fillers.hip: VALU fillers of the SAME wave between MFMAs\n")
         f.write(logtext("fillers.log"))
+        f.write("## tools/ubench/valu_rate.hip: issue cost of the epilogue's VALU instructions with no MFMA in flight\n")
+        f.write(logtext("valu_rate.log"))
 
 
 def tree():
