@@ -14,8 +14,8 @@
 //               below the 2^-24 relative rounding of the fp32 accumulation that every fp32 kernel has as well.
 //   A position's scale depends on that position only, so its result does not depend on its neighbours in the batch.
 // The activation image lives in LDS already split (hi plane + lo plane = the 4 bytes per element of an fp32
-// image), channel-contiguous so that a B operand is one 16-byte LDS read.  4 positions per workgroup; its 4 waves are a
-// 2 x 2 grid (64 output channels x 64 cells each in the default 3-position form).  A lane keeps its own entries of x in fp32
+// image), channel-contiguous so that a B operand is one 16-byte LDS read.  3 positions per workgroup in the product form
+// (126 cells on 128 MFMA columns); its 4 waves are a 2 x 2 grid of 64 output channels x 64 cells.  A lane keeps its own entries of x in fp32
 // registers for the residual, t = SiLU(BN(conv3x3(x))) goes through the image and the 1x1 convolution is the same
 // routine with one tap.  Prototypes and measurements: tools/ubench/{conv,block}_split_f16.hip, tools/k3_accuracy.py,
 // tools/split_fp16_accuracy.py; DESIGN.md section 4.
@@ -89,9 +89,9 @@ __device__ unsigned long long g_split_ts[4][64];
 #define SMFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)    // the heads
 
 // A convolution over the split image as 9 (3x3) or 1 (1x1) taps x PER_TAP k-slices of 32 channels; slice sl = tap * PER_TAP
-// + cs.  The wave computes channel fragments fbase .. fbase + 3 for its 96 cells.  The weight fragments of a slice come
-// from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
-// 64 channels x 96 cells asks for half the weight bytes per MFMA that 128 x 48 does.
+// + cs.  The wave computes channel fragments fbase .. fbase + SMF - 1 for its 32 SNF cells.  The weight fragments of a slice
+// come from L2 through the vector memory path, which serves the four waves of a CU one after the other: a wave tile of
+// 64 channels x 64 (or 96) cells asks for half the weight bytes per MFMA that 128 x 48 does.
 // NKH: k-steps of 16 per slice that hold anything (the stem's 3 input planes sit in the first one)
 // The weights of a convolution's FIRST slice, requested by the caller before the barriers that publish the convolution's input
 // image: they do not depend on it, and a convolution that starts by asking for them waits a whole L2 round trip with an idle
@@ -292,8 +292,9 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
             }
 }
 
-// NS positions per workgroup, NW waves.  The 42 NS cells are cut into column groups of 96 (NWB of them), the 128 channels into
-// NW / NWB groups; a wave owns one (channel group, column group) tile.
+// NS positions per workgroup, NW waves.  The 42 NS cells are cut into NWB column groups of 32 SNF, the 128 channels into
+// NW / NWB groups; a wave owns one (channel group, column group) tile.  <3, 4> is the product form (SPLIT_DEFAULT_CFG); the
+// others are kept for measurement (AZ_K3_SPLIT_CFG; DESIGN.md 4.2 has all four side by side).
 //   <4, 4>  one workgroup per CU, one wave per SIMD: wave tile 64 channels x 96 cells, up to 512 registers per lane
 //   <2, 4>  TWO workgroups per CU (80 KB of LDS and 256 registers per lane each): wave tile 32 channels x 96 cells (84 live).  A
 //           SIMD holds one wave of each workgroup, so one workgroup's epilogue arithmetic (SiLU, split, image stores) and operand
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         }
     }
     __syncthreads();
-    // wave (wa, wb): channels 64 wa .. 64 wa + 63 (32-channel fragments 2 wa, 2 wa + 1) x cells 96 wb .. 96 wb + 95
+    // wave (wa, wb): channels 32 SMF wa .. (32-channel fragments SMF wa ..) x cells 32 SNF wb ..
     const int wa = wave % NWA, wb = wave / NWA, fbase = SMF * wa, l32 = lane & 31, kg = lane >> 5, ch0 = 32 * SMF * wa + 4 * kg;
     int brow[SNF], crow[SNF], cpos[SNF];
     bool live[SNF];

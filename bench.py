@@ -297,7 +297,10 @@ def main(argv=None):
         # global game ids: rank + world * k, so the RNG streams of a job's games do not depend on how it is split
         e = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                            reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
-                           game_id_base=rank, game_id_stride=world, n_cohorts=args.cohorts)
+                           game_id_base=rank, game_id_stride=world,
+                           # engine default (3 cohorts at 2 048 slots) suits the product kernel; the fp32 Winograd kernel
+                           # (5 positions per workgroup, 3 x longer launches) measured best with 4
+                           n_cohorts=args.cohorts or (4 if k3 == "wino" and G >= 2048 else 0))
         e.load_net(blob, kernel=k3)
         return e
 

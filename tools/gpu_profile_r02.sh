@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 2: one GPU-box session that produces what profiles/r02_* keeps.  Every rocprofv3 pass is a run of its own (PMC
 # passes are never combined with tracing), every step has its own time limit, and the script stops at the first failure.
-# Usage (on the GPU box, from the repo root): bash tools/gpu_profile_r02.sh [part]    part: bench | k3 | tree | all
+# Usage (on the GPU box, from the repo root): bash tools/gpu_profile_r02.sh [part]    part: bench | k3 | k3extra | tree | all
 set -uo pipefail
 PART=${1:-all}
 O=gpurun_out/prof_r02
@@ -31,6 +31,10 @@ if [ $PART = k3 ] || [ $PART = all ]; then
   timeout -k 5 60 ./dbgbuild/coexec > $O/coexec.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/fillers > $O/fillers.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/valu_rate > $O/valu_rate.log 2>&1 || exit 1
+fi
+if [ $PART = k3 ] || [ $PART = all ] || [ $PART = k3extra ]; then
+  # the same stamps on the operand-removal builds: equal cycles per workgroup, shorter launches = a higher clock
+  for v in AZ_K3S_DBG_NOW+AZ_K3S_DBG_TS AZ_K3S_DBG_NOB+AZ_K3S_DBG_TS; do echo "== $v" >> $O/k3_stamps_variants.log; AZAMD_LIB=dbgbuild/libazamd_$v.so timeout -k 10 100 python3 tools/k3s_stamps.py 6144 2>&1 | grep "total\|entry" >> $O/k3_stamps_variants.log || exit 1; AZAMD_LIB=dbgbuild/libazamd_$v.so timeout -k 10 100 python3 tools/k3_sweep.py 6144 2>&1 | grep "n=" >> $O/k3_stamps_variants.log || exit 1; done
 fi
 if [ $PART = tree ] || [ $PART = all ]; then
   T="python3 tools/bench_configs.py k1 ttt nbttt pure unpack"

@@ -109,6 +109,10 @@ def k3():
         f.write(logtext("k3_variants.log"))
         f.write("## in-kernel shader-clock stamps (tools/k3s_stamps.py, build -DAZ_K3S_DBG_TS)\n")
         f.write(logtext("k3_stamps.log"))
+        f.write("## the same stamps and the launch time of the operand-removal builds (constant operands: no weight loads / no LDS "
+                "operand reads): the workgroup takes the SAME number of cycles, the launch is shorter -> the clock is higher: the "
+                "kernel runs against the chip's power limit, not against a pipe\n")
+        f.write(logtext("k3_stamps_variants.log"))
         f.write("## tools/ubench/coexec.hip: one wave's MFMAs and ANOTHER wave's VALU work on the same SIMD\n")
         f.write(logtext("coexec.log"))
         f.write("## tools/ubench/fillers.hip: VALU fillers of the SAME wave between MFMAs\n")
