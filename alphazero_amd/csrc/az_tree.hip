@@ -552,16 +552,17 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
 // BS: workgroup size.  Under the CNN workload every CU is held by a K3 workgroup that owns its whole register file, so a
 // tree-step workgroup waits for a CU to come free: fewer, larger workgroups (512 threads = 64 Connect4 games) need
 // fewer CUs and start sooner.
+// Two shapes of the same kernel (round 2, A/B runs on one box with tools/bench_ab.sh):
+//   k_tree_step       512 threads, as many registers as it likes (176).  It cannot share a CU with a K3 workgroup (384 registers
+//                     per lane), so its workgroups wait for CUs that K3 workgroups have left: 68 us per launch instead of 8.
+//   k_tree_step_small 256 threads capped at 128 registers per lane (37 dwords of scratch).  It fits BESIDE a K3 workgroup and
+//                     starts at once -- and the K3 workgroup that shares its CU's issue ports runs longer.
+// 2 048 slots in 3 cohorts (the bench): the big shape wins, 897 against 866 games/s; the GPU is bound by K3 workgroup time and
+// the tree step's wait sits in a cohort's chain only.  16 384 slots in 4 cohorts (cfg3): the tree steps are a quarter of the
+// GPU's work, the CUs they hold alone are missed, and the small shape wins, 750 against 720 games/s.  launch_tree_step picks by
+// the number of games per launch.
 template <class G, int BS>
-// (Measured, round 2: a 256-thread tree step capped at 128 registers per lane -- AZ_TREE_STEP_VGPR=128, AZ_TREE_STEP_BS=256 --
-// fits on a CU beside a K3 workgroup and starts at once, 8 us instead of 68; the bench LOSES 3.5 % with it, 866 against 897
-// games/s on one box: the GPU is bound by K3 workgroup time, and a tree step sharing a CU's issue ports slows that K3 workgroup.)
-#ifdef AZ_TREE_STEP_VGPR
-#define AZ_TREE_STEP_ATTR __attribute__((amdgpu_waves_per_eu(512 / AZ_TREE_STEP_VGPR, 8)))
-#else
-#define AZ_TREE_STEP_ATTR
-#endif
-__global__ __launch_bounds__(BS) AZ_TREE_STEP_ATTR void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
+__device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clear_count, const Roll& r) {
     constexpr int LG = G::LG, GPB = BS / LG;
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
@@ -582,6 +583,15 @@ __global__ __launch_bounds__(BS) AZ_TREE_STEP_ATTR void k_tree_step(Dev d, int m
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
     }
+}
+template <class G, int BS>
+__global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
+    tree_step_body<G, BS>(d, mode, clear_count, r);
+}
+template <class G>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tree_step_small(Dev d, int mode, u32* clear_count,
+                                                                                                    Roll r) {
+    tree_step_body<G, 256>(d, mode, clear_count, r);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -898,14 +908,24 @@ int launch_search_pure(const Dev& d, int n_sims, hipStream_t st) {
 #ifndef AZ_TREE_STEP_BS
 #define AZ_TREE_STEP_BS 512
 #endif
+#ifndef AZ_TREE_STEP_SMALL_FROM
+#define AZ_TREE_STEP_SMALL_FROM 1000   // games per launch from which the small shape is used (683 per launch: big wins 895 : 870; 1 024: small wins 905 : 850)
+#endif
 // mode 2 = select, 1 = backup, 3 = backup of playout i then select of playout i+1
 static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_t st, const Roll* roll = nullptr) {
     Roll r;
     memset(&r, 0, sizeof(r));
     if (roll) r = *roll;
     AZ_DISPATCH_GAME(game_of(d), {
-        constexpr int BS = AZ_TREE_STEP_BS, gpb = BS / GT::LG;
-        k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count, r);
+        static const char* shape = getenv("AZ_TREE_STEP");   // "big" / "small": measurement hook
+        const bool small = shape ? shape[0] == 's' : d.gn >= AZ_TREE_STEP_SMALL_FROM;
+        if (small) {
+            constexpr int gpb = 256 / GT::LG;
+            k_tree_step_small<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count, r);
+        } else {
+            constexpr int BS = AZ_TREE_STEP_BS, gpb = BS / GT::LG;
+            k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count, r);
+        }
     });
     AZ_HIP(hipGetLastError());
     return AZ_OK;
