@@ -169,6 +169,27 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
         fetch_at(bb, cs * 32, sl * (2 * SMFT * 2048), b, a_from_pre);
     };
     auto mfmas = [&](int b) {  // product by product: 6 independent accumulators between two uses of the same one
+#ifdef AZ_K3S_DBG_LOADONLY   // diagnostic builds only: every operand is fetched as usual and kept alive, the MFMAs multiply constants
+        // (results are garbage).  Against the NOW+NOB build (no fetches, constant operands) this prices the operand TRAFFIC alone;
+        // against the product build it prices the bits toggling inside the matrix pipe.
+        const f16x8 ca = (f16x8)((_Float16)0.25f), cb = (f16x8)((_Float16)0.5f);
+#pragma unroll
+        for (int kh = 0; kh < NKH; kh++) {
+#pragma unroll
+            for (int f = 0; f < SMF; f++) asm volatile("" ::"v"(ah[b][kh][f]), "v"(al[b][kh][f]));
+#pragma unroll
+            for (int j = 0; j < SNF; j++) {
+                asm volatile("" ::"v"(bh[b][kh][j]));
+                if (LO_INPUT) asm volatile("" ::"v"(bl[b][kh][j]));
+            }
+#pragma unroll
+            for (int rep = 0; rep < (LO_INPUT ? 3 : 2); rep++)
+#pragma unroll
+                for (int f = 0; f < SMF; f++)
+#pragma unroll
+                    for (int j = 0; j < SNF; j++) SMFMA(ca, cb, acc[f][j]);
+        }
+#else
 #pragma unroll
         for (int kh = 0; kh < NKH; kh++) {
 #pragma unroll
@@ -186,6 +207,7 @@ __device__ inline void conv_split(const f16x8* __restrict__ w, const _Float16* h
 #pragma unroll
                 for (int j = 0; j < SNF; j++) SMFMA(al[b][kh][f], bh[b][kh][j], acc[f][j]);
         }
+#endif
     };
     // One basic block per pair of slices: the fetches are UNCONDITIONAL (the slice index is clamped; the last pair of an even
     // count fetches the last slice once more), because a conditional fetch is a block of 20 loads of its own during which the

@@ -53,6 +53,11 @@ EXEC_FLOP_PER_LEAF = 15740 * 4 * 2048 / 5.0
 # 3.4 MB of Winograd-form weights fetched once per XCD L2 per launch; positions in and outputs out are ~25 KB.
 K3_TRAFFIC_BYTES_PER_LAUNCH = (2 * 13544.8 + 33.4) * 1024
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+# What the fp16 matrix pipes SUSTAIN on this chip is set by its power limit and depends on the operand data
+# (tools/ubench/mfma_power.hip, every SIMD issuing v_mfma_f32_32x32x16_f16 back to back; profiles/r02_k3_split_breakdown.txt):
+# zeros 1.9 PFLOP/s at 1.84 GHz, random mantissas 1.46-1.50, values spread like K3's operands 1.31-1.37 at 1.27-1.33 GHz.
+# roofline.peak stays the data-sheet figure; the measured ceiling is reported beside it.
+SUSTAINED_F16_MFMA_TFLOPS_REAL_DATA = 1340.0
 SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi)
 # HBM bytes per launch of the split kernel in THIS workload (PMC passes on bench.py itself, profiles/r02_k3_pmc.txt:
 # FETCH_SIZE 8271.7 KB x 2 + WRITE_SIZE 18.1 KB): the 2.0 MB of split weights once per XCD L2 per launch; positions in
@@ -401,6 +406,10 @@ def main(argv=None):
                     "unit": "TFLOP/s", "frac": 3 * alg / PEAK_F16_MFMA_TFLOPS, "traffic": K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH,
                     "traffic_source": K3_SPLIT_TRAFFIC_SOURCE,
                     "fp32_equivalent_tflops": alg, "fp32_equivalent_frac_of_f32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS,
+                    "sustained_peak_real_data": SUSTAINED_F16_MFMA_TFLOPS_REAL_DATA,
+                    "frac_of_sustained_peak_real_data": 3 * alg / SUSTAINED_F16_MFMA_TFLOPS_REAL_DATA,
+                    "sustained_peak_source": "tools/ubench/mfma_power.hip, profiles/r02_k3_split_breakdown.txt: all SIMDs "
+                                             "issuing back to back on K3-like operand values, 1.27-1.33 GHz (power limit)",
                     "executed_flop_per_leaf": SPLIT_FLOP_PER_LEAF, "algorithm": info["algorithm"]}
         else:
             roof = {"bound": "mfma", "kernel": info["kernel"], "achieved": alg,

@@ -26,11 +26,12 @@ if [ $PART = k3 ] || [ $PART = all ]; then
   run timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE -d $O/k3_write -o pmc -- python3 tools/k3_sweep.py 6144 > $O/k3_write.log 2>&1
   # un-profiled timings: the kernel configurations side by side, the operand-removal builds, the in-kernel stamps
   for c in 34 44 24 48; do echo "== cfg $c" >> $O/k3_cfgs.log; AZ_K3_SPLIT_CFG=$c timeout -k 10 100 python3 tools/k3_sweep.py 1024 6144 16384 2>&1 | grep "n=" >> $O/k3_cfgs.log || exit 1; done
-  for v in AZ_K3S_DBG_NOW AZ_K3S_DBG_NOB AZ_K3S_DBG_NOW+AZ_K3S_DBG_NOB; do echo "== $v" >> $O/k3_variants.log; AZAMD_LIB=dbgbuild/libazamd_$v.so timeout -k 10 100 python3 tools/k3_sweep.py 6144 2>&1 | grep "n=" >> $O/k3_variants.log || exit 1; done
+  for v in AZ_K3S_DBG_NOW AZ_K3S_DBG_NOB AZ_K3S_DBG_NOW+AZ_K3S_DBG_NOB AZ_K3S_DBG_LOADONLY; do echo "== $v" >> $O/k3_variants.log; AZAMD_LIB=dbgbuild/libazamd_$v.so timeout -k 10 100 python3 tools/k3_sweep.py 6144 2>&1 | grep "n=" >> $O/k3_variants.log || exit 1; done
   AZAMD_LIB=dbgbuild/libazamd_AZ_K3S_DBG_TS.so timeout -k 10 100 python3 tools/k3s_stamps.py 6144 > $O/k3_stamps.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/coexec > $O/coexec.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/fillers > $O/fillers.log 2>&1 || exit 1
   timeout -k 5 60 ./dbgbuild/valu_rate > $O/valu_rate.log 2>&1 || exit 1
+  timeout -k 5 120 ./dbgbuild/mfma_power > $O/mfma_power.log 2>&1 || exit 1
 fi
 if [ $PART = k3 ] || [ $PART = all ] || [ $PART = k3extra ]; then
   # the same stamps on the operand-removal builds: equal cycles per workgroup, shorter launches = a higher clock

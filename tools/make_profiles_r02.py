@@ -55,13 +55,16 @@ def bench():
         f.write("# rocprofv3 --kernel-trace --stats -- %s   (headline kernel: split-fp16 K3, 3 positions per workgroup)\n" % cmd)
         db = os.path.join(O, "bench", "bench_results.db")
         f.write(cap(rs.kernel_stats, db))
-        f.write("## one round of a cohort on its HIP stream: K3 launch -> tree step -> next K3 launch\n")
+        f.write("## one round of a cohort on its HIP stream: K3 launch -> tree step -> next K3 launch, whole trace (mostly the pre-roll, "
+                "whose staggered start parks part of the slots: smaller launches)\n")
         f.write(cap(rs.chain_stats, db))
+        f.write("## the same over the last 12 % of the trace = the 4 timed steps (all slots live)\n")
+        f.write(cap(rs.chain_stats, db, 0.12))
         f.write("## bench.py JSON line of this (profiled) run:\n" + open(os.path.join(O, "bench_line.json")).read())
         f.write("\n# the same with the fp32 Winograd K3 (bench.py --k3 wino)\n")
         db = os.path.join(O, "bench_wino", "bench_results.db")
         f.write(cap(rs.kernel_stats, db))
-        f.write(cap(rs.chain_stats, db))
+        f.write(cap(rs.chain_stats, db, 0.12))
         f.write("## bench.py JSON line of that run:\n" + open(os.path.join(O, "bench_wino_line.json")).read())
 
 
@@ -105,7 +108,7 @@ def k3():
         f.write("## tools/k3_sweep.py with AZ_K3_SPLIT_CFG = <positions per workgroup><waves>: 34 is the product configuration\n")
         f.write(logtext("k3_cfgs.log"))
         f.write("## operand-removal builds (tools/k3_variants.sh; results are garbage, timing only): NOW = no weight loads, NOB = no LDS "
-                "operand reads\n")
+                "operand reads, LOADONLY = every operand fetched as usual but the MFMAs multiply constants\n")
         f.write(logtext("k3_variants.log"))
         f.write("## in-kernel shader-clock stamps (tools/k3s_stamps.py, build -DAZ_K3S_DBG_TS)\n")
         f.write(logtext("k3_stamps.log"))
@@ -117,6 +120,9 @@ def k3():
         f.write(logtext("coexec.log"))
         f.write("## tools/ubench/fillers.hip: VALU fillers of the SAME wave between MFMAs\n")
         f.write(logtext("fillers.log"))
+        f.write("## tools/ubench/mfma_power.hip: every SIMD issuing v_mfma_f32_32x32x16_f16 back to back -- the sustained clock and rate "
+                "depend on the operand DATA\n")
+        f.write(logtext("mfma_power.log"))
         f.write("## tools/ubench/valu_rate.hip: issue cost of the epilogue's VALU instructions with no MFMA in flight\n")
         f.write(logtext("valu_rate.log"))
 

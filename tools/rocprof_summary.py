@@ -37,9 +37,11 @@ def kernel_stats(db):
         print("%-70s %14.1f %14.1f %8.2fx" % (name.split("(")[0][-70:], busy / 1e3, tot / 1e3, tot / max(busy, 1)))
 
 
-def chain_stats(db):
+def chain_stats(db, tail=1.0):
     """per HIP stream (= engine cohort): how one round of the rolling self-play spends its time.  A cohort's round is the
-    chain K3 launch -> tree step -> next K3 launch; the gaps are the time between a kernel's end and its successor's start."""
+    chain K3 launch -> tree step -> next K3 launch; the gaps are the time between a kernel's end and its successor's start.
+    tail < 1: only the dispatches of the last `tail` of the traced time span (the bench's timed window: the untimed pre-roll
+    before it runs with part of the slots parked, i.e. with smaller K3 launches)."""
     c = sqlite3.connect(db)
     cols = [d[0] for d in c.execute("select * from kernels limit 1").description]
     key = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
@@ -47,6 +49,11 @@ def chain_stats(db):
     if key is None:
         return
     rows = list(c.execute("select %s, name, start, end from kernels order by start" % key))
+    if tail < 1.0 and rows:
+        t_lo, t_hi = rows[0][2], max(r[3] for r in rows)
+        cut = t_hi - tail * (t_hi - t_lo)
+        rows = [r for r in rows if r[2] >= cut]
+        print("# only dispatches that start in the last %.0f %% of the traced span (%d of them)" % (100 * tail, len(rows)))
     by = {}
     for q, name, a, b in rows:
         by.setdefault(q, []).append((a, b, "k3" if "cnn_forward" in name else ("tree" if "tree_step" in name else "other")))
