@@ -113,6 +113,23 @@ def test_instant_augment_mirrors_batch(dropin):
         dropin.load("TTT").instant_augment(tuple(torch.from_numpy(x) for x in c4[:5]))
 
 
+def test_instant_augment_vs_reference_fixture(dropin):
+    """the drop-in's instant_augment against tensors recorded from the reference's own functions (Connect4/utils.py:114-128,
+    TTT/utils.py:74-89; tests/golden/augment.npz, made by make_fixtures_augment.py): same values, shapes and dtypes."""
+    import torch
+    d = np.load(os.path.join(G, "augment.npz"))
+    for game, key in (("Connect4", "c4"), ("TTT", "ttt")):
+        aug = dropin.load(game).instant_augment
+        for B in (1, 5, 64):
+            batch = tuple(torch.from_numpy(d["%s/%d/in%d" % (key, B, i)]) for i in range(6))
+            out = aug(batch)
+            assert len(out) == 6
+            for i, o in enumerate(out):
+                want = d["%s/%d/out%d" % (key, B, i)]
+                assert o.dtype == torch.from_numpy(want).dtype and tuple(o.shape) == want.shape, (game, B, i)
+                assert np.array_equal(o.numpy(), want), (game, B, i)
+
+
 def test_replaybuffer_hands_out_the_reference_rows(dropin):
     """dropin/ReplayBuffer.py vs rows recorded from the reference's ReplayBuffer (tests/golden/replay.npz, made by
     make_fixtures_replay.py): same plies stored, same torch / numpy seeds -> the same rows in the same order from
