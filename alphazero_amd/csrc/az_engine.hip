@@ -415,7 +415,9 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         return AZ_ERR_ARG;
     }
     AZ_TRY(use_device(cfg->device));
-    AZ_TRY(static_stage_init(cfg->device));
+    // the staging memory of az_net_forward_static is looked up here, outside that entry point's hot path; an engine that
+    // never calls it is not refused over it (a device ordinal beyond the table: az_net_forward_static returns AZ_ERR_STATE)
+    (void)static_stage_init(cfg->device);
     az_engine* e = new az_engine();
     e->cfg = *cfg;
     e->gi = gi;
@@ -1196,12 +1198,20 @@ int az_net_load(az_engine* e, const float* blob, size_t n_floats) {
         set_error("az_net_load: the CNN is the Connect4 network");
         return AZ_ERR_ARG;
     }
-    AZ_HIP(hipStreamSynchronize(e->stream));
-    if (e->net) {
-        cnn_destroy(e->net);
-        e->net = nullptr;
+    // the new network is built beside the live one and swapped in only when the blob was accepted: a refused blob (wrong
+    // size, a NaN from a diverged training step) leaves the engine searching on the weights it had
+    Cnn* fresh = nullptr;
+    AZ_TRY(cnn_create(blob, n_floats, e->k3_kind, &fresh));
+    hipError_t he = hipStreamSynchronize(e->stream);
+    for (int c = 1; c < e->C && he == hipSuccess; c++) he = hipStreamSynchronize(e->cstream[c]);
+    if (he != hipSuccess) {
+        cnn_destroy(fresh);
+        set_error(std::string("az_net_load: hipStreamSynchronize: ") + hipGetErrorString(he));
+        return AZ_ERR_HIP;
     }
-    return cnn_create(blob, n_floats, e->k3_kind, &e->net);
+    if (e->net) cnn_destroy(e->net);
+    e->net = fresh;
+    return AZ_OK;
 }
 
 int az_net_set_kernel(az_engine* e, int kind) {
@@ -1261,7 +1271,7 @@ int az_net_forward_static(az_engine* e, int64_t n, const uint64_t* states, float
         return AZ_ERR_ARG;
     }
     if (n == 0) return AZ_OK;
-    StaticStage* st = g_stage[e->cfg.device];   // set by az_engine_create on this device
+    StaticStage* st = e->cfg.device < MAX_DEVICES ? g_stage[e->cfg.device] : nullptr;   // set by az_engine_create on this device
     if (!st) {
         set_error("az_net_forward_static: static staging memory was not initialised on this device");
         return AZ_ERR_STATE;

@@ -405,6 +405,9 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
     constexpr int LG = G::LG;
     const u32 flags = d.leaf_flags[g];
     if (!(flags & 8u)) return false;
+    // a slot parked (az_set_active) while it holds a delivered leaf keeps the leaf, its path and the evaluator's answer (all
+    // indexed by slot, nothing else writes them) until it is resumed: parking never advances ply, tree or trajectory
+    if (!d.active[g]) return false;
     uint4* nodes = d.nodes + (i64)g * d.cap;
     Leaf lf;
     lf.hint = 0;
@@ -492,6 +495,8 @@ __device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int
 template <class G>
 __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
     constexpr int LG = G::LG;
+    // an idle slot (parked, or its game is over and was not refilled) is left exactly as it is -- a parked leaf stays parked
+    if (!d.active[g]) return;
     // at most r.cap terminal playouts are finished in place per round: a game whose search has converged on a forced
     // line ends ~all of its playouts on terminal nodes, and the launch lasts as long as its slowest game
     for (int it = 0; it <= r.cap; it++) {
@@ -862,18 +867,23 @@ __global__ __launch_bounds__(256) void k_puct(i64 n, const i32* Np, const i32* n
 
 static inline int game_of(const Dev& d) { return d.game; }
 
-// games per wave of the fused searches (a game is touched only by its own lane group, so results do not depend on it);
-// AZ_TREE_GPW overrides the default (measurement hook).
+// games per wave of the fused searches (a game is touched only by its own lane group, so results do not depend on it).
+// Always a power of two that one of the instantiated kernels has (8 / 4 / 2 / 1), so the grid computed from it matches the
+// kernel that is launched; AZ_TREE_GPW overrides the default (measurement hook) and is rounded DOWN to such a value.
+#ifndef AZ_TREE_GPW_FULL_FROM
+#define AZ_TREE_GPW_FULL_FROM 0x7fffffff   // games per launch from which full waves are used (see the table in pick_gpw)
+#endif
 template <class GT>
-static int pick_gpw(const Dev&) {
+static int pick_gpw(const Dev& d) {
     constexpr int full = 64 / GT::LG;
     static const char* env = getenv("AZ_TREE_GPW");
     // default: half-filled waves.  A wave lasts as long as its slowest game, and with fewer games per wave less of it idles
     // behind the deepest walk / longest rollout (measured, full -> half -> quarter: NBTTT 8 192 x 800 7.24 / 6.31 / 10.7 ms,
     // pure MCTS 4 096 x 1 000 26.2 / 22.9 / 22.8 ms, TicTacToe 4 096 x 100 0.428 / 0.433 / 0.519 ms)
-    int gpw = env ? atoi(env) : full / 2;
+    int gpw = env ? atoi(env) : (d.G >= AZ_TREE_GPW_FULL_FROM ? full : full / 2);
     if (gpw < 1) gpw = 1;
     if (gpw > full) gpw = full;
+    while (gpw & (gpw - 1)) gpw &= gpw - 1;   // round down to a power of two
     return gpw;
 }
 

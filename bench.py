@@ -17,6 +17,16 @@ non-terminal leaf per live game; --mode lockstep runs one ply of every slot per 
 parity tests pin against the reference; both produce the same games (tests/test_gpu_cnn.py).  Finished trajectories
 are packed, all-gathered over RCCL (N>1) and expanded into ReplayBuffer-shaped tensors inside the timed region.
 
+Other first-class workloads (same contract, same line format; the default stays configs[2] so that the driver's N = 1
+scaling point and its bench line are the same measurement):
+  --config 3   BASELINE configs[3], one GPU's share: the same Connect4 CNN self-play with 16 384 slots per GPU (38.5 GB
+               node pool); with --gpus N the N-GPU job of configs[3]
+  --config 4   BASELINE configs[4]: nine-board tic-tac-toe self-play, 800 playouts per move, hashed evaluator (the reference
+               has no usable NBTTT network), 2 random opening plies per game drawn from the game id, c_puct 1.5, tree
+               reuse, node pool sized for whole games (16 384 slots = 153 GB of the 288 GB); a step = one ply of every
+               slot = ONE fused-search launch (k_search_fused<NBTTT>) + the ply end; roofline = that kernel, HBM class
+(AZ_BENCH_CONFIG=3|4 in the environment selects them when the command line cannot.)
+
 value (games/s) = games that FINISH inside the timed window / wall time.  So that a window of a few game
 lengths means something, an untimed pre-roll de-synchronises the slots first: the first games start staggered over one
 mean game length (az_set_active) and play on until as many games have finished as there are slots, so the window sees
@@ -65,6 +75,11 @@ SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product
 K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8271.7 + 18.1) * 1024
 K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r02_k3_pmc.txt"
 DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# HBM bytes per k_search_fused<NBTTT> launch at 16 384 games x 800 playouts from the PMC passes of tools/gpu_profile_r03.sh
+# (profiles/r03_tree_env_pmc.txt); None until measured for the shape in use
+CFG4_TRAFFIC_BYTES_PER_LAUNCH = None
+CFG4_TRAFFIC_SOURCE = None
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -124,6 +139,36 @@ def cpu_baseline(blob, n_playout, mean_len, budget_s=15.0, multi_budget_s=None):
                                 sample="%d threads x independent game sequences, %d moves in %.1f s" %
                                        (cores, sum(r[0] for r in res), dtm))
     return out
+
+
+def cpu_baseline_nbttt(n_playout, mean_len, eval_seed, budget_s=12.0):
+    """cpu_baseline leg of --config 4: the C port's sequential search on nine-board tic-tac-toe with the same hashed
+    evaluator, whole moves of self-play games from seeded 2-ply openings on ONE host core until the budget is used."""
+    from oracle import oracle as orc
+    t = orc.MCTS("NBTTT", c_init=1.5, n_playout=n_playout, eval_kind=orc.EVAL_HASH, eval_seed=eval_seed)
+    rng = np.random.default_rng(0)
+
+    def opening():
+        b, a1 = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+        return orc.Env.nbttt_open(b, a1, int(rng.integers(0, 8)))
+    env = opening()
+    t0 = time.perf_counter()
+    moves, games = 0, 1
+    while time.perf_counter() - t0 < budget_s:
+        if env.done():
+            env = opening()
+            t.reset()
+            games += 1
+        acts, vis = t.get_action_visits(env)
+        a = acts[int(np.argmax(vis))]
+        t.prune_root(a)
+        env.step(a)
+        moves += 1
+    dt = time.perf_counter() - t0
+    sims_s = t.stat_playouts / dt
+    return dict(value=sims_s / (n_playout * mean_len), unit="games/s", cores=1, kind="port", sims_per_s=sims_s,
+                sample="%d moves x %d playouts over %d NBTTT self-play game(s) (%.1f s), oracle/az_oracle.c, hashed evaluator, "
+                       "1 thread; games/s = sims/s / (%d * %.1f plies)" % (moves, n_playout, games, dt, n_playout, mean_len))
 
 
 def cpu_baseline_pure(n_playout=1000, searches=6):
@@ -242,8 +287,11 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--games", type=int, default=2048, help="concurrent game slots per GPU")
-    ap.add_argument("--playouts", type=int, default=500)
+    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=int(os.environ.get("AZ_BENCH_CONFIG", "2") or 2),
+                    help="BASELINE.json configs[i]: 2 = Connect4 CNN self-play, 2048 slots/GPU (default, the headline); 3 = the "
+                         "same with 16384 slots/GPU; 4 = NBTTT x 800 playouts, hashed evaluator, deep trees")
+    ap.add_argument("--games", type=int, default=0, help="concurrent game slots per GPU (0 = the configuration's: 2048 / 16384 / 16384)")
+    ap.add_argument("--playouts", type=int, default=0, help="playouts per move (0 = the configuration's: 500 / 500 / 800)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--cohort", type=int, default=512, help="games of the untimed cohort that measures plies/game")
@@ -291,7 +339,17 @@ def main(argv=None):
     from alphazero_amd.collector import ReplaySink, TrajectoryGatherer
     from alphazero_amd.engine import SelfPlayEngine
 
-    G, S = args.games, args.playouts
+    cfgi = args.config
+    nb = cfgi == 4                    # nine-board tic-tac-toe on the fused tree kernel; else Connect4 + CNN
+    G = args.games or {2: 2048, 3: 16384, 4: 16384}[cfgi]
+    S = args.playouts or (800 if nb else 500)
+    FIRST_N = 12 if nb else 10        # NBTTT/config.py: first_n_steps 12; Connect4/config.py: 10
+    GAME = "NBTTT" if nb else "Connect4"
+    if nb:
+        args.mode = "lockstep"        # synthetic evaluators run the fused search: one launch per ply of every slot
+        args.no_second_leg = True
+    if cfgi == 3:
+        args.no_second_leg = True     # the fp32 leg belongs to the headline configuration
     dev = torch.device("cuda", local)
     blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "weights", "AZ_Connect4_CNN_current.f32"), dtype="<f4")
     # The engine comes first: a process has few hardware queues (GPU_MAX_HW_QUEUES) and HIP hands them to streams in
@@ -300,6 +358,9 @@ def main(argv=None):
     # under torch.distributed.run with the group initialised first: 374 ms per step instead of 280).
     def make_engine(k3):
         # global game ids: rank + world * k, so the RNG streams of a job's games do not depend on how it is split
+        if nb:
+            return SelfPlayEngine("NBTTT", n_games=G, n_playout=S, c_puct=1.5, evaluator="hash", eval_seed=7, reuse_tree=True,
+                                  move="sample", rng_seed=0, device=local, game_id_base=rank, game_id_stride=world)
         e = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                            reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
                            game_id_base=rank, game_id_stride=world,
@@ -317,7 +378,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: --gpus %d but RCCL reports %d ranks" % (args.gpus, dist.get_world_size()))
-    sink = ReplaySink("Connect4", capacity=1 << 20, device=dev)
+    sink = ReplaySink(GAME, capacity=1 << 20, device=dev)
 
     def all_min(x):
         if not use_dist:
@@ -338,9 +399,9 @@ def main(argv=None):
 
         def one_step():
             if args.mode == "rolling":
-                eng.selfplay_rounds(S, temp=1.0, first_n_steps=10, refill=True)
+                eng.selfplay_rounds(S, temp=1.0, first_n_steps=FIRST_N, refill=True)
             else:
-                eng.selfplay_step(temp=1.0, first_n_steps=10, refill=True)
+                eng.selfplay_step(temp=1.0, first_n_steps=FIRST_N, refill=True)
             eng.sync()
             recs = gather.gather()          # pack on device -> all_gather (RCCL) -> records of every rank
             sink.store_packed(recs)         # expand into ReplayBuffer-shaped tensors on device
@@ -352,7 +413,9 @@ def main(argv=None):
         # Every rank runs the same number of steps (they hold collectives).
         pre_steps = 0
         if args.preroll != 0:
-            T0 = 22 if args.preroll < 0 else max(1, min(22, args.preroll))
+            # mean game duration in steps: rolling Connect4 22 (above); lockstep = one ply per step: Connect4 33, NBTTT 30
+            TG = 22 if args.mode == "rolling" else (30 if nb else 33)
+            T0 = TG if args.preroll < 0 else max(1, min(TG, args.preroll))
             limit = 6 * T0 if args.preroll < 0 else args.preroll
             start_step = np.arange(G) % T0
             eng.reset_stats()
@@ -366,7 +429,8 @@ def main(argv=None):
         for _ in range(warmup):
             one_step()
         eng.reset_stats()
-        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all else 2))   # 2: HIP events around the K3 launches only
+        # 2: HIP events around the K3 launches only; the fused-search workload has one launch per step: time them all
+        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all or nb else 2))
         stored0 = sink.total_stored
         barrier()
         t0 = time.perf_counter()
@@ -380,15 +444,35 @@ def main(argv=None):
         # aggregate over ranks: MAX time, SUM of work
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         work = torch.tensor([st["plies"], st["playouts"], st["games_finished"], st["leaf_evals"], st["levels"],
-                             st["terminal_hits"]], dtype=torch.float64, device=dev)
+                             st["terminal_hits"], st["children"]], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(work, op=dist.ReduceOp.SUM)
-        r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term"), [float(x) for x in work.tolist()]))
+        r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term", "children"), [float(x) for x in work.tolist()]))
         r.update(dt=float(tmax.item()), prof=prof, stored=sink.total_stored - stored0, pre_steps=pre_steps, k3=k3)
         return r
 
+    def roofline_tree(m):
+        """--config 4: the fused search kernel, HBM class.  Algorithmic bytes per playout from the run's own
+        counters (16-byte node records): select levels * (16 k + 8), backup (levels + playouts) * 8,
+        expand children * 16 + evals * 4, k = children per expansion; achieved = those bytes of this rank's launches /
+        the launches' summed duration (HIP events on the engine stream; one launch at a time, nothing overlaps it)."""
+        f = m["prof"]["fused"]
+        k = m["children"] / max(m["evals"], 1)
+        by = (m["levels"] * (16.0 * k + 8.0) + (m["levels"] + m["playouts"]) * 8.0 + m["children"] * 16.0 + m["evals"] * 4.0) / world
+        gbs = by / (max(f["ms"], 1e-9) * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "k_search_fused<NBTTT>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": CFG4_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": CFG4_TRAFFIC_SOURCE,
+                "avg_launch_ms": f["ms"] / max(f["launches"], 1), "launches": f["launches"],
+                "algorithmic_bytes_per_launch": by / max(f["launches"], 1),
+                "bytes_per_playout": by * world / max(m["playouts"], 1), "mean_children": k,
+                "playouts_per_launch": m["playouts"] / world / max(f["launches"], 1),
+                "note": "pointer chase over per-game arenas: the launch is bound by issue slots / dependent-load latency, not "
+                        "HBM (DESIGN.md 4.1); algorithmic bytes priced against the HBM peak as SURVEY 8d asks"}
+
     def roofline(m, k3):
+        if nb:
+            return roofline_tree(m)
         cnn = m["prof"]["cnn"]
         evals_rank = m["evals"] / world
         cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
@@ -432,11 +516,20 @@ def main(argv=None):
     else:
         cohort = min(G, args.cohort)
         eng.traj_fetch(clear=True)
-        n_done = (eng.selfplay_rolling if args.mode == "rolling" else eng.selfplay)(cohort, temp=1.0, first_n_steps=10)
+        n_done = (eng.selfplay_rolling if args.mode == "rolling" else eng.selfplay)(cohort, temp=1.0, first_n_steps=FIRST_N)
         cg, cp = eng.traj_count()
         assert cg == n_done == cohort, (cg, n_done, cohort)
         mean_len = cp / cg
 
+    gathered = "; trajectories all-gathered over RCCL into ReplayBuffer tensors" if world > 1 else ""
+    if nb:
+        workload = ("NBTTT (nine-board tic-tac-toe) self-play, %d concurrent games/GPU x %d playouts/move, hashed evaluator, 2 "
+                    "random opening plies per game keyed by game id, c_puct 1.5, tree reuse, %.0f GB node pool/GPU "
+                    "(BASELINE configs[4]%s)" % (G, S, eng.nodes_per_game * 16.0 * G / 1e9, gathered))
+    else:
+        workload = ("Connect4 CNN self-play, %d concurrent games/GPU x %d playouts/move, real AZ_Connect4_CNN_current "
+                    "weights, Dirichlet 0.7, random flips, tree reuse (BASELINE configs[%d]%s)"
+                    % (G, S, 2 if cfgi == 2 else 3, gathered))
     if rank == 0:
         games_s = m["finished"] / m["dt"]           # games that finish inside the window / wall
         est = (m["plies"] / m["dt"]) / mean_len
@@ -444,32 +537,32 @@ def main(argv=None):
             "metric": "selfplay_games_per_sec", "value": games_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": K3_INFO[args.k3]["dtype"], "data": "synthetic",
+            "dtype": "f32 tree statistics / u64 bitboards (PUCT select, expand, backup; no network)" if nb else K3_INFO[args.k3]["dtype"],
+            "data": "synthetic",
             "value_steady_state_estimate": est,
             "sims_per_sec": m["playouts"] / m["dt"],
-            "config": {"workload": "Connect4 CNN self-play, %d concurrent games/GPU x %d playouts/move, real "
-                                   "AZ_Connect4_CNN_current weights, Dirichlet 0.7, random flips, tree reuse "
-                                   "(BASELINE configs[2]%s)" % (G, S, "; trajectories all-gathered over RCCL into "
-                                                                "ReplayBuffer tensors" if world > 1 else ""),
-                       "mode": args.mode, "k3": args.k3, "games_per_gpu": G, "playouts_per_move": S,
+            "config": {"workload": workload,
+                       "baseline_config": cfgi, "mode": args.mode, "k3": None if nb else args.k3, "games_per_gpu": G, "playouts_per_move": S,
                        "launcher": ("bench.py (self-launched ranks)" if os.environ.get("AZ_BENCH_SELF_LAUNCHED")
                                     else ("torch.distributed.run" if use_dist else "single process")),
                        "rccl_ranks": dist.get_world_size() if use_dist else None,
                        "preroll_steps_untimed": m["pre_steps"],
-                       "preroll": "first games staggered over 22 steps, then until >= 2 x games_per_gpu games finished on every rank"
+                       "preroll": "first games staggered over one mean game duration, then until >= 2 x games_per_gpu games finished on every rank"
                                   if args.preroll < 0 else ("none" if args.preroll == 0 else "staggered, fixed length"),
                        "mean_plies_per_game": mean_len,
                        "games_finished_in_window": m["finished"], "slot_plies_in_window": m["plies"],
                        "leaf_evals": m["evals"], "terminal_hits": m["term"],
                        "mean_tree_depth": m["levels"] / max(m["playouts"], 1),
                        "plies_stored_in_replay": m["stored"],
-                       "x_reference_python_1thread": games_s / REF_PY_GAMES_PER_S},
+                       # the reference's Python was timed on configs[0]'s game (Connect4, real net); no NBTTT figure exists
+                       "x_reference_python_1thread": None if nb else games_s / REF_PY_GAMES_PER_S},
             "roofline": roofline(m, args.k3),
             "kernel_time_ms": {k: v["ms"] for k, v in m["prof"].items()},
             "box": _box_info(torch, local),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(blob, S, mean_len, args.cpu_budget)
+            out["cpu_baseline"] = (cpu_baseline_nbttt(S, mean_len, 7, args.cpu_budget) if nb
+                                   else cpu_baseline(blob, S, mean_len, args.cpu_budget))
             out["config"]["x_cpu_port_1core"] = games_s / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["config"]["x_cpu_port_all_cores"] = games_s / out["cpu_baseline"]["all_cores"]["value"]

@@ -83,7 +83,7 @@ typedef struct az_config {
     int64_t nodes_per_game; /* arena capacity in nodes; 0 = 1 + A*S*(reuse ? max_plies : 1)               */
     uint64_t game_id_base;  /* global id of the first game (slot 0); keys the RNG streams; see game_id_stride */
     int32_t n_cohorts;      /* AZ_EVAL_CNN: slot ranges searched on their own HIP streams so that one range's  */
-                            /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 2048 slots, 3 from 768), max 4.   */
+                            /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 4096 slots, 3 from 768, 2 from 512), max 4. */
                             /* Results do not depend on it (games are independent).                            */
     uint64_t game_id_stride; /* the k-th game this engine starts (slots first, then refills) has the global id      */
                             /* game_id_base + game_id_stride * k; 0 = 1.  Multi-GPU: base = rank, stride = world size, */
@@ -205,7 +205,9 @@ int64_t az_selfplay_rolling(az_engine *e, int64_t n_games_target, double temp, i
 /* total number of games az_selfplay_step's refill may start (0 = unlimited). */
 int az_set_game_target(az_engine *e, int64_t n_games_target);
 /* park (mask[g] == 0) or resume (mask[g] != 0) slots between calls: a parked slot takes no part in search, ply ends or
- * refill and keeps its game and tree; a slot whose game is over stays idle until a refill restarts it.  No counterpart in
+ * refill and keeps its game and tree; a slot whose game is over stays idle until a refill restarts it.  In rolling mode a
+ * slot parked while it holds a delivered leaf keeps that leaf (and the network's answer to it) untouched: the playout is
+ * backed up in the first round after the slot is resumed, so parking never advances ply, tree or trajectory.  No counterpart in
  * the reference (one game at a time); az_selfplay parks surplus slots with it and bench.py staggers the first games so
  * that the timed window sees slots at every game age.  Synchronises. */
 int az_set_active(az_engine *e, const uint8_t *mask);
@@ -246,7 +248,9 @@ int az_net_forward(az_engine *e, int64_t n, const uint64_t *states, float *logp,
  * the n positions and the four outputs in a fixed device array inside the library (352 KiB per GPU, held until the
  * process ends) and calls no hipMalloc / hipFree.  Same arguments, same kernels, bit-identical outputs.
  * n > AZ_NET_FORWARD_STATIC_MAX is AZ_ERR_ARG.  Every call on a GPU shares that GPU's array: calls that overlap in time
- * on one GPU (two host threads, two engines) race -- serialise them. */
+ * on one GPU (two host threads, two engines) race -- serialise them.  The array's address is looked up once per device
+ * (az_engine_create) and cached for the life of the process: after a hipDeviceReset it is stale, do not call this again.
+ * Devices with an ordinal >= 64 have no staging slot: AZ_ERR_STATE. */
 #define AZ_NET_FORWARD_STATIC_MAX 4096
 int az_net_forward_static(az_engine *e, int64_t n, const uint64_t *states, float *logp, float *logv, float *probs,
                           float *value);
