@@ -30,13 +30,13 @@ class az_config(C.Structure):
         ("flip_mode", C.c_int32), ("reuse_tree", C.c_int32), ("dirichlet_alpha", C.c_double),
         ("rng_seed", C.c_uint64), ("move_mode", C.c_int32), ("max_plies", C.c_int32),
         ("nodes_per_game", C.c_int64), ("game_id_base", C.c_uint64), ("n_cohorts", C.c_int32),
-        ("game_id_stride", C.c_uint64),
+        ("game_id_stride", C.c_uint64), ("eval_cache_entries", C.c_int64),
     ]
 
 
 class az_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("playouts", "levels", "leaf_evals", "terminal_hits", "children",
-                                         "nodes_used", "games_finished", "plies", "rollout_plies")]
+                                         "nodes_used", "games_finished", "plies", "rollout_plies", "cache_hits")]
 
 
 _P = C.POINTER

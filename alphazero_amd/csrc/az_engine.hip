@@ -134,6 +134,7 @@ struct az_engine {
     u8* d_flags8 = nullptr;
     Cnn* net = nullptr;
     int k3_kind = AZ_K3_DEFAULT;   // az_net_set_kernel
+    u64 cache_loads = 0;           // az_net_load calls so far: part of the evaluation cache's epoch
     unsigned long long target = 0;
     int recording = 0;
     // rolling self-play (az_selfplay_rounds): leaves are parked between calls; parity of the leaf counter in use
@@ -142,8 +143,8 @@ struct az_engine {
     // cohorts: the slots are cut into C ranges whose select -> CNN -> backup chains run on their own streams, so one
     // cohort's tree kernels and the ragged last round of its CNN launch overlap with the other cohort's CNN launch.
     int C = 1;
-    hipStream_t cstream[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[AZ_MAX_COHORTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cstream[AZ_MAX_COHORTS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[AZ_MAX_COHORTS] = {};
     // live kernel timing with HIP events on the engine stream (az_set_profiling / az_get_profile)
     int prof_on = 0;      // mask of the categories being timed
     bool prof_skip = true;
@@ -532,6 +533,31 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         (void)hipMemcpy(dt64, t64.data(), t64.size() * sizeof(double2), hipMemcpyHostToDevice);
         d.tab64 = dt64;
     }
+    // evaluation cache (az_tree.hip "Evaluation cache"): AZ_EVAL_CNN engines, unless switched off.  Auto size: 32 Ki entries
+    // per slot (a game evaluates ~8 k distinct positions; room for several generations of games), 2^16 .. 2^26 entries of 64 B
+    e->cfg.eval_cache_entries = -1;
+    {
+        static const char* cenv = getenv("AZ_EVAL_CACHE");   // "0": off whatever the configuration says (A/B runs); "n": 2^n entries
+        i64 want = cfg->eval_cache_entries;
+        if (cenv && atoi(cenv) == 0) want = -1;
+        else if (cenv && atoi(cenv) > 0 && want == 0) want = 1ll << std::min(atoi(cenv), 31);
+        if (cfg->evaluator == AZ_EVAL_CNN && want >= 0) {
+            if (want == 0) want = std::min<i64>(std::max<i64>(G * 32768, 1ll << 16), 1ll << 26);
+            i64 n = 1;
+            while (n < want && n < (1ll << 31)) n <<= 1;
+            uint4* tab = nullptr;
+            int rcc = e->dalloc(&tab, (size_t)n * 4);
+            if (rcc != AZ_OK) {
+                az_engine_destroy(e);
+                return rcc;
+            }
+            // zeroed: hipMalloc may hand back a table of an engine that was destroyed earlier in this process
+            (void)hipMemset(tab, 0, (size_t)n * 64);
+            d.cache = tab;
+            d.cache_mask = (u64)n - 1;
+            e->cfg.eval_cache_entries = n;
+        }
+    }
     hipError_t he = hipStreamCreate(&e->stream);
     // cohorts only pay off where an evaluator launch sits between select and backup (AZ_EVAL_CNN)
     int C = cfg->n_cohorts;
@@ -635,6 +661,7 @@ int az_get_stats(az_engine* e, az_stats* out) {
     out->games_finished = (i64)st[ST_GAMES];
     out->plies = (i64)st[ST_PLIES];
     out->rollout_plies = (i64)st[ST_ROLLOUT_PLIES];
+    out->cache_hits = (i64)st[ST_CACHE_HITS];
     return AZ_OK;
 }
 
@@ -1211,6 +1238,10 @@ int az_net_load(az_engine* e, const float* blob, size_t n_floats) {
     }
     if (e->net) cnn_destroy(e->net);
     e->net = fresh;
+    // new weights (or another K3 kernel: its bits differ in the last place): every entry of the evaluation cache is stale.
+    // The epoch is folded into the entries' tags, so none of them validates any more; nothing is cleared.
+    e->cache_loads++;
+    e->d.cache_epoch = mix64(0xA24BAED4963EE407ull + e->cache_loads * 0x9FB21C651E98DF25ull + (u64)(uintptr_t)e);
     return AZ_OK;
 }
 

@@ -25,7 +25,7 @@ __host__ __device__ inline u32 link_first(u32 l) { return l & LINK_FIRST_MASK; }
 __host__ __device__ inline u32 link_nchild(u32 l) { return (l >> 24) & 15u; }
 __host__ __device__ inline u32 link_action(u32 l) { return l >> 28; }
 
-enum StatIdx { ST_PLAYOUTS = 0, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CHILDREN, ST_GAMES, ST_PLIES, ST_ROLLOUT_PLIES, ST_N };
+enum StatIdx { ST_PLAYOUTS = 0, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CHILDREN, ST_GAMES, ST_PLIES, ST_ROLLOUT_PLIES, ST_CACHE_HITS, ST_N };
 
 // Everything a kernel needs, passed by value (all pointers are device memory).
 struct Dev {
@@ -74,6 +74,11 @@ struct Dev {
     i32* ply;             // [G]
     unsigned long long* stats;  // [ST_N]
     u32* err;             // [1] bit0 arena overflow, bit1 puct table overflow
+    // evaluation cache (AZ_EVAL_CNN; az_tree.hip "Evaluation cache"): direct-mapped table of 64-byte entries shared by all
+    // the games of the engine, or null
+    uint4* cache;         // [cache_mask + 1][4]
+    u64 cache_mask;       // entries - 1 (a power of two)
+    u64 cache_epoch;      // folded into every entry's tags: changes with every az_net_load, which empties the table at once
 };
 
 struct CnnDev;  // az_cnn.hip

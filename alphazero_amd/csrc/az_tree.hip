@@ -91,26 +91,32 @@ __device__ inline float rng_uniform(u64 seed, u64 gid, u64 ctr, u32 stream) {
 }
 
 // Gamma(alpha, 1) sample, Marsaglia-Tsang with the alpha<1 boost; statistical parity only (np.random.dirichlet,
-// MCTS.py:156).  Each child lane draws its own variate from its own counter stream.
+// MCTS.py:156).  Each child lane draws its own variate from its own counter stream.  The sampler runs at EVERY expansion of a
+// train-mode search (MCTS.py:155-157), i.e. once per non-terminal playout, inside the tree step's dependent chain: its
+// logarithms, cosine, square root and power are the hardware's approximations (v_log_f32, v_cos_f32, v_sqrt_f32, v_exp_f32:
+// ~1 ulp-class errors that a statistical contract does not see) instead of libm's correctly rounded routines, which were
+// several hundred instructions per expansion.
+__device__ inline float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }   // v_log_f32 is log2
 __device__ inline float rng_gamma(float alpha, u64 seed, u64 gid, u64 ctr, u32 lane) {
     float a = alpha < 1.f ? alpha + 1.f : alpha;
-    float dd = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * dd), x = dd;
+    float dd = a - 1.0f / 3.0f, c = __builtin_amdgcn_rsqf(9.0f * dd), x = dd;
     for (u32 it = 0; it < 32; it++) {
         float u1 = rng_uniform(seed, gid, ctr, 0x100u + lane * 128u + it * 3u);
         float u2 = rng_uniform(seed, gid, ctr, 0x101u + lane * 128u + it * 3u);
         float u3 = rng_uniform(seed, gid, ctr, 0x102u + lane * 128u + it * 3u);
-        float n = sqrtf(-2.f * logf(u1 + 5.9604645e-8f)) * cosf(6.2831853f * u2);  // Box-Muller
+        // Box-Muller; v_cos_f32 takes its argument in revolutions: cos(2 pi u2)
+        float n = __builtin_amdgcn_sqrtf(-2.f * fast_ln(u1 + 5.9604645e-8f)) * __builtin_amdgcn_cosf(u2);
         float v = 1.f + c * n;
         if (v <= 0.f) continue;
         v = v * v * v;
-        if (logf(u3 + 5.9604645e-8f) < 0.5f * n * n + dd - dd * v + dd * logf(v)) {
+        if (fast_ln(u3 + 5.9604645e-8f) < 0.5f * n * n + dd - dd * v + dd * fast_ln(v)) {
             x = dd * v;
             break;
         }
     }
     if (alpha < 1.f) {
         float u = rng_uniform(seed, gid, ctr, 0x1000u + lane);
-        x *= powf(u + 5.9604645e-8f, 1.f / alpha);
+        x *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u + 5.9604645e-8f) * __builtin_amdgcn_rcpf(alpha));   // u^(1/alpha)
     }
     return x;
 }
@@ -300,6 +306,59 @@ __device__ inline void finish(const Dev& d, int g, uint4* nodes, const typename 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Evaluation cache (AZ_EVAL_CNN).  CNN.predict (Network.py:78-85) is a pure function of the evaluated (possibly mirrored)
+// position, and K3's result for a position does not depend on where the position sits in a batch (tests/test_gpu_cnn.py:
+// bit-identical), so a table keyed by the 16-byte position can answer a repeated leaf with exactly the bits K3 would produce:
+// every game's trajectory is the same, bit for bit, with the cache on, off, hit or missed.  Self-play games from one network
+// share most of their early and a good part of their later positions (measured with tools/leaf_duplicates.py on the bench's
+// workload: 62 % of the leaves of 1 024 concurrent games had been evaluated before by some game, 14 % by the same game), so
+// the table is shared by all the games of the engine.  The reference evaluates every leaf anew (MCTS.py:146).
+//
+// Direct-mapped, 64-byte entries, newest wins.  An entry is four 16-byte chunks of {3 data words, tag}:
+//     data = w0.lo w0.hi w1.lo | w1.hi p0 p1 | p2 p3 p4 | p5 p6 value            (position words, CNN probs over all 7 actions, value)
+//     tag_i = hi32(kh) ^ fold(chunk i's three data words) + i,   kh = mix64(w0 ^ mix64(w1 ^ epoch))
+// Writers (any group of any wave, no locks, no atomics) store the four chunks; a reader accepts an entry only if every chunk
+// carries the tag that ITS OWN data and the probed position give and the stored position equals the probed one.  A chunk torn
+// between two writers, or chunks of two different writers in one entry, fail their tags (2^-32 per chunk to pass by chance,
+// and the full position is compared on top); two writers of the same position write identical bytes.  `epoch` changes with
+// every az_net_load: entries of the previous weights stop validating at once, nothing has to be cleared.
+// ------------------------------------------------------------------------------------------------------------
+__device__ inline u64 cache_hash(const Dev& d, u64 w0, u64 w1) { return mix64(w0 ^ mix64(w1 ^ d.cache_epoch)); }
+__device__ inline u32 cache_tag(u64 kh, u32 a, u32 b, u32 c, u32 i) {
+    const u32 f = (a * 0x9E3779B1u) ^ (((b << 11) | (b >> 21)) * 0x85EBCA77u) ^ (((c << 23) | (c >> 9)) * 0xC2B2AE3Du);
+    return ((u32)(kh >> 32) ^ f) + i + 1u;
+}
+// probe for position (w0, w1): true and probs[7] / value filled on a hit.  Every lane of the group asks for the same 64 bytes.
+__device__ inline bool cache_probe(const Dev& d, u64 w0, u64 w1, float* probs, float& value) {
+    const u64 kh = cache_hash(d, w0, w1);
+    const uint4* e = d.cache + (kh & d.cache_mask) * 4;
+    const uint4 c0 = e[0], c1 = e[1], c2 = e[2], c3 = e[3];
+    bool ok = c0.x == (u32)w0 && c0.y == (u32)(w0 >> 32) && c0.z == (u32)w1 && c1.x == (u32)(w1 >> 32);
+    ok = ok && c0.w == cache_tag(kh, c0.x, c0.y, c0.z, 0u) && c1.w == cache_tag(kh, c1.x, c1.y, c1.z, 1u) &&
+         c2.w == cache_tag(kh, c2.x, c2.y, c2.z, 2u) && c3.w == cache_tag(kh, c3.x, c3.y, c3.z, 3u);
+    probs[0] = as_f(c1.y);
+    probs[1] = as_f(c1.z);
+    probs[2] = as_f(c2.x);
+    probs[3] = as_f(c2.y);
+    probs[4] = as_f(c2.z);
+    probs[5] = as_f(c3.x);
+    probs[6] = as_f(c3.y);
+    value = as_f(c3.z);
+    return ok;
+}
+// store K3's answer for position (w0, w1): lane i < 4 of the group writes chunk i
+__device__ inline void cache_insert(const Dev& d, u64 w0, u64 w1, const float* probs, float value, int gl) {
+    if (gl >= 4) return;
+    const u64 kh = cache_hash(d, w0, w1);
+    u32 a, b, c;
+    if (gl == 0) a = (u32)w0, b = (u32)(w0 >> 32), c = (u32)w1;
+    else if (gl == 1) a = (u32)(w1 >> 32), b = as_u(probs[0]), c = as_u(probs[1]);
+    else if (gl == 2) a = as_u(probs[2]), b = as_u(probs[3]), c = as_u(probs[4]);
+    else a = as_u(probs[5]), b = as_u(probs[6]), c = as_u(value);
+    d.cache[(kh & d.cache_mask) * 4 + gl] = make_uint4(a, b, c, cache_tag(kh, a, b, c, (u32)gl));
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Fused search: n_sims complete playouts per game in ONE launch (evaluator computed in-kernel).
 // ------------------------------------------------------------------------------------------------------------
 // GPW = games per wavefront: 64 / LG fills every lane; fewer games per wave (down to one: the other lanes exit at once) put the
@@ -359,12 +418,32 @@ __global__ __launch_bounds__(256) void k_search_fused(Dev d, int n_sims) {
     }
 }
 
+// Statistics of the split-search kernels: counted per game in registers and added to the global counters ONCE per launch and
+// wave.  (One atomicAdd per playout and counter, as round 2 had it, is a few thousand same-address atomics per launch; they
+// serialise in L2 and -- with several playouts per game and launch since the evaluation cache -- were most of the tree step's
+// duration: the step got SLOWER when its games were spread over more waves.)
+struct Cnt {
+    u32 playouts = 0, levels = 0, evals = 0, term = 0, hits = 0, children = 0;
+};
+__device__ inline void flush_counts(const Dev& d, const Cnt& c, int gl) {
+    const u64 act = __ballot(1), leaders = __ballot(gl == 0);
+    const int first = __ffsll((long long)act) - 1;
+    const u32 v[6] = {c.playouts, c.levels, c.evals, c.term, c.hits, c.children};
+    const int idx[6] = {ST_PLAYOUTS, ST_LEVELS, ST_EVALS, ST_TERMINAL, ST_CACHE_HITS, ST_CHILDREN};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u32 sum = 0;
+        for (u64 mm = leaders; mm; mm &= mm - 1) sum += (u32)__shfl((int)v[i], __ffsll((long long)mm) - 1);
+        if ((int)__lane_id() == first && sum) atomicAdd(&d.stats[idx[i]], (unsigned long long)sum);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Split search: select -> (evaluator kernel or host) -> backup, one playout per game per round.
 // ------------------------------------------------------------------------------------------------------------
 // Bodies of the two halves; `p_*` are this group's LDS path rows.
 template <class G>
-__device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+__device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt) {
     constexpr int LG = G::LG;
     if (!d.active[g]) {
         if (gl == 0) d.leaf_flags[g] = 0u;
@@ -379,6 +458,11 @@ __device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32*
     u32 fpos = d.flip_pos[g];
     u64 ctr = d.sim_ctr[g];
     leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+    float cprobs[G::A], cvalue = 0.f;
+    bool hit = false;
+    if constexpr (G::GAME == AZ_GAME_C4) {
+        if (d.cache && !(lf.flags & 1u)) hit = cache_probe(d, aug.w[0], aug.w[1], cprobs, cvalue);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int dd = gl; dd <= lf.depth; dd += LG) {  // path: LDS -> HBM, coalesced
         d.path_idx[(i64)g * G::MAXD + dd] = p_idx[dd];
@@ -389,19 +473,23 @@ __device__ inline void select_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 #pragma unroll
         for (int i = 0; i < G::W; i++) d.leaf_state[(i64)g * G::W + i] = aug.w[i];
         d.leaf_depth[g] = lf.depth;
-        d.leaf_flags[g] = lf.flags | 8u;
+        d.leaf_flags[g] = lf.flags | 8u | (hit ? 16u : 0u);
         d.leaf_tvalue[g] = lf.tvalue;
         d.flip_pos[g] = fpos;
-        if (!(lf.flags & 1u)) {
+        if (hit) {   // the network's answer to this position is in the table: hand it to the backup as if K3 had written it
+#pragma unroll
+            for (int a = 0; a < G::A; a++) d.eval_probs[(i64)g * G::A + a] = cprobs[a];
+            d.eval_value[g] = cvalue;
+        } else if (!(lf.flags & 1u)) {
             u32 pos = atomicAdd(d.eval_count, 1u);  // compaction: only non-terminal leaves reach the network
             d.eval_list[pos] = (u32)g;
         }
-        atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
+        cnt.levels += (u32)lf.depth;
     }
 }
 
 template <class G>
-__device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+__device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt) {
     constexpr int LG = G::LG;
     const u32 flags = d.leaf_flags[g];
     if (!(flags & 8u)) return false;
@@ -430,6 +518,9 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 #pragma unroll
         for (int a = 0; a < G::A; a++) probs[a] = d.eval_probs[(i64)g * G::A + a];
         value = d.eval_value[g];
+        if constexpr (G::GAME == AZ_GAME_C4) {
+            if (d.cache && !(flags & 16u)) cache_insert(d, aug.w[0], aug.w[1], probs, value, gl);   // K3's answer, fresh
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < G::A; a++) probs[a] = 0.f;
@@ -445,9 +536,11 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
         d.n_alloc[g] = nalloc;
         d.sim_ctr[g] = ctr + 1;
         d.leaf_flags[g] = 0u;
-        atomicAdd(&d.stats[ST_PLAYOUTS], 1ull);
-        atomicAdd(&d.stats[(flags & 1u) ? ST_TERMINAL : ST_EVALS], 1ull);
-        atomicAdd(&d.stats[ST_CHILDREN], (unsigned long long)st_children);
+        cnt.playouts++;
+        if (flags & 1u) cnt.term++;
+        else if (flags & 16u) cnt.hits++;
+        else cnt.evals++;
+        cnt.children += st_children;
     }
     return true;
 }
@@ -473,45 +566,63 @@ struct Roll {
     Play p;
 };
 
-// one playout of game g's current move has just been backed up: count it; at the S-th, end the ply.
+// the move of game g is complete (its S-th playout has been backed up): AlphaZeroPlayer.get_action's tail + Game's ply
+// (player.py:104-116, game.py:41-58) + the slot's refill, by the game's own lane group
 template <class G>
-__device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int gl) {
+__device__ inline void roll_ply_end(const Dev& d, const Roll& r, int g, int gl) {
     if (gl == 0) {
-        int ms = d.move_sims[g] + 1;
-        if (ms >= r.S) {
-            ms = 0;
-            float pi[G::A];
-            const double T = (r.first_n >= 0 && d.ply[g] >= r.first_n) ? 1e-3 : r.temp;   // game.py:41
-            const int a = choose_game<G>(d, g, T, r.move_mode, pi, 1);
-            if (a >= 0) advance_game<G>(d, r.p, g, a, pi, 1, r.reuse, 1);
-            if (r.target) refill_game<G>(d, r.p, g, r.target, r.gid_base);   // only acts on a finished slot
-        }
-        d.move_sims[g] = ms;
+        float pi[G::A];
+        const double T = (r.first_n >= 0 && d.ply[g] >= r.first_n) ? 1e-3 : r.temp;   // game.py:41
+        const int a = choose_game<G>(d, g, T, r.move_mode, pi, 1);
+        if (a >= 0) advance_game<G>(d, r.p, g, a, pi, 1, r.reuse, 1);
+        if (r.target) refill_game<G>(d, r.p, g, r.target, r.gid_base);   // only acts on a finished slot
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// select for rolling self-play: walk until a NON-terminal leaf is found (terminal playouts are completed in place)
+// one playout of game g's current move has just been backed up: count it; at the S-th, end the ply.
 template <class G>
-__device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+__device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int gl) {
+    const int ms = d.move_sims[g] + 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (gl == 0) d.move_sims[g] = ms >= r.S ? 0 : ms;
+    if (ms >= r.S) roll_ply_end<G>(d, r, g, gl);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// select for rolling self-play: walk until a leaf is found that needs the network.  Playouts that end on a terminal node, or
+// on a position whose evaluation is in the cache, are completed in place (at most r.cap of them per round: a game whose
+// search has converged on a forced line ends ~all of its playouts on terminal nodes, and the launch lasts as long as its
+// slowest game).  The game's state -- root position, root statistics, allocation mark, counters -- lives in registers from
+// one playout to the next (as in the fused kernel) and goes back to memory at a ply end and at the end of the round: a
+// playout's dependent chain is then the walk itself plus one table probe.
+template <class G>
+__device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt) {
     constexpr int LG = G::LG;
     // an idle slot (parked, or its game is over and was not refilled) is left exactly as it is -- a parked leaf stays parked
     if (!d.active[g]) return;
-    // at most r.cap terminal playouts are finished in place per round: a game whose search has converged on a forced
-    // line ends ~all of its playouts on terminal nodes, and the launch lasts as long as its slowest game
+    uint4* nodes = d.nodes + (i64)g * d.cap;
+    typename G::State rs = load_root_state<G>(d, g);
+    u32 root = d.root[g], nalloc = d.n_alloc[g], fpos = d.flip_pos[g];
+    u64 ctr = d.sim_ctr[g];
+    int ms = d.move_sims[g];
+    uint4 rr = nodes[root];
+    u32 rN = rr.x, rlink = rr.w;
+    float rQ = as_f(rr.y);
+    bool parked = false;
     for (int it = 0; it <= r.cap; it++) {
-        if (!d.active[g]) break;
-        uint4* nodes = d.nodes + (i64)g * d.cap;
-        typename G::State s = load_root_state<G>(d, g);
-        const u32 root = d.root[g];
-        uint4 rr = nodes[root];
-        Leaf lf = walk<G>(d, nodes, s, root, rr.x, as_f(rr.y), rr.w, gl, p_idx, p_N, p_Q);
+        typename G::State s = rs;   // env.copy()
+        Leaf lf = walk<G>(d, nodes, s, root, rN, rQ, rlink, gl, p_idx, p_N, p_Q);
         typename G::State aug;
-        u32 fpos = d.flip_pos[g];
-        u64 ctr = d.sim_ctr[g];
         leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
+        float probs[G::A], cvalue = 0.f;
+        bool hit = false;
+        if constexpr (G::GAME == AZ_GAME_C4) {
+            if (d.cache && !(lf.flags & 1u)) hit = cache_probe(d, aug.w[0], aug.w[1], probs, cvalue);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (!(lf.flags & 1u)) {  // a leaf for the network: park the playout exactly like select_body
+        cnt.levels += (u32)lf.depth;
+        if (!(lf.flags & 1u) && !hit) {  // a leaf for the network: park the playout exactly like select_body
             for (int dd = gl; dd <= lf.depth; dd += LG) {
                 d.path_idx[(i64)g * G::MAXD + dd] = p_idx[dd];
                 d.path_N[(i64)g * G::MAXD + dd] = p_N[dd];
@@ -523,32 +634,53 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
                 d.leaf_depth[g] = lf.depth;
                 d.leaf_flags[g] = lf.flags | 8u;
                 d.leaf_tvalue[g] = lf.tvalue;
-                d.flip_pos[g] = fpos;
                 u32 pos = atomicAdd(d.eval_count, 1u);
                 d.eval_list[pos] = (u32)g;
-                atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
             }
-            return;
+            parked = true;
+            break;
         }
-        // terminal leaf: MCTS.py:159-164 right away (no expansion, the constant value is backed up)
-        float probs[G::A];
+        // terminal leaf: MCTS.py:159-164 right away (no expansion, the constant value is backed up); a leaf whose evaluation
+        // is in the table: MCTS.py:147-164 right away with the table's probs and value (the bits K3 would deliver)
+        if (!hit) {
 #pragma unroll
-        for (int a = 0; a < G::A; a++) probs[a] = 0.f;
-        u32 nalloc = d.n_alloc[g], rN = rr.x, rlink = rr.w, st_children = 0;
-        float rQ = as_f(rr.y);
-        finish<G>(d, g, nodes, aug, lf, probs, 0.f, gl, nalloc, root, rN, rQ, rlink, p_idx, p_N, p_Q, ctr, st_children);
-        if (gl == 0) {
-            d.sim_ctr[g] = ctr + 1;
-            d.flip_pos[g] = fpos;
-            d.leaf_flags[g] = 0u;
-            atomicAdd(&d.stats[ST_LEVELS], (unsigned long long)lf.depth);
-            atomicAdd(&d.stats[ST_PLAYOUTS], 1ull);
-            atomicAdd(&d.stats[ST_TERMINAL], 1ull);
+            for (int a = 0; a < G::A; a++) probs[a] = 0.f;
         }
+        u32 st_children = 0;
+        finish<G>(d, g, nodes, aug, lf, probs, cvalue, gl, nalloc, root, rN, rQ, rlink, p_idx, p_N, p_Q, ctr, st_children);
+        ctr++;
+        cnt.playouts++;
+        if (hit) cnt.hits++, cnt.children += st_children;
+        else cnt.term++;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        roll_playout_done<G>(d, r, g, gl);
+        if (++ms >= r.S) {   // the move is complete: state back to memory, ply end, and the new root's state in again
+            ms = 0;
+            if (gl == 0) {
+                d.n_alloc[g] = nalloc;
+                d.sim_ctr[g] = ctr;
+                d.flip_pos[g] = fpos;
+                d.move_sims[g] = 0;
+                d.leaf_flags[g] = 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            roll_ply_end<G>(d, r, g, gl);
+            if (!d.active[g]) return;   // the game is over and the slot was not refilled; everything is in memory
+            rs = load_root_state<G>(d, g);
+            root = d.root[g];
+            nalloc = d.n_alloc[g];
+            fpos = d.flip_pos[g];
+            ctr = d.sim_ctr[g];
+            rr = nodes[root];
+            rN = rr.x, rlink = rr.w, rQ = as_f(rr.y);
+        }
     }
-    if (gl == 0) d.leaf_flags[g] = 0u;   // no leaf for the network this round
+    if (gl == 0) {
+        d.n_alloc[g] = nalloc;
+        d.sim_ctr[g] = ctr;
+        d.flip_pos[g] = fpos;
+        d.move_sims[g] = ms;
+        if (!parked) d.leaf_flags[g] = 0u;   // no leaf for the network this round
+    }
 }
 
 // mode bit0: backup of the evaluated playout, bit1: select of the next one.  Between two evaluator launches the
@@ -566,32 +698,40 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
 // the tree step's wait sits in a cohort's chain only.  16 384 slots in 4 cohorts (cfg3): the tree steps are a quarter of the
 // GPU's work, the CUs they hold alone are missed, and the small shape wins, 750 against 720 games/s.  launch_tree_step picks by
 // the number of games per launch.
-template <class G, int BS>
+// GPW: games per wavefront (64 / LG fills every lane).  A wave runs the union of its games' paths -- the deepest walk, every
+// branch any of them takes, as many in-place playouts as its busiest game -- so with fewer games per wave each game waits
+// for fewer others; the tree step is far from filling the chip (2 048 games are 256 full waves), so the extra waves are free.
+template <class G, int BS, int GPW = 64 / G::LG>
 __device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clear_count, const Roll& r) {
-    constexpr int LG = G::LG, GPB = BS / LG;
+    constexpr int LG = G::LG, GPB = (BS / 64) * GPW;
+    static_assert(GPW * LG <= 64, "lane groups of one wave");
     __shared__ u32 s_idx[GPB][G::MAXD];
     __shared__ u32 s_N[GPB][G::MAXD];
     __shared__ float s_Q[GPB][G::MAXD];
     // clear_count: a leaf counter that the evaluator has already consumed and that nothing in THIS launch counts
     // into (the select half of this launch counts into d.eval_count, which is a different counter: see the engine).
     if (clear_count && blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0u;
-    const int grp = threadIdx.x / LG, gl = threadIdx.x % LG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= GPW * LG) return;
+    const int grp = wave * GPW + lane / LG, gl = lane % LG;
     const int g = d.g0 + blockIdx.x * GPB + grp;
     if (g >= d.g0 + d.gn) return;
     bool played = false;
-    if (mode & 1) played = backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+    Cnt cnt;
+    if (mode & 1) played = backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
     if (r.on) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (played) roll_playout_done<G>(d, r, g, gl);
-        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
     } else if (mode & 2) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp]);
+        select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
     }
+    flush_counts(d, cnt, gl);
 }
-template <class G, int BS>
+template <class G, int BS, int GPW = 64 / G::LG>
 __global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
-    tree_step_body<G, BS>(d, mode, clear_count, r);
+    tree_step_body<G, BS, GPW>(d, mode, clear_count, r);
 }
 template <class G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tree_step_small(Dev d, int mode, u32* clear_count,
@@ -933,8 +1073,16 @@ static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_
             constexpr int gpb = 256 / GT::LG;
             k_tree_step_small<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count, r);
         } else {
-            constexpr int BS = AZ_TREE_STEP_BS, gpb = BS / GT::LG;
-            k_tree_step<GT, BS><<<dim3((d.gn + gpb - 1) / gpb), dim3(BS), 0, st>>>(d, mode, clear_count, r);
+            constexpr int BS = AZ_TREE_STEP_BS, full = 64 / GT::LG;
+            static const char* genv = getenv("AZ_TREE_STEP_GPW");   // measurement hook: games per wave of the big shape
+            int gpw = genv ? atoi(genv) : full;
+            gpw = gpw >= full ? full : (gpw >= full / 2 ? full / 2 : (gpw >= full / 4 && full / 4 >= 1 ? full / 4 : 1));
+            const int gpb = (BS / 64) * gpw;
+            const dim3 grid((d.gn + gpb - 1) / gpb), blk(BS);
+            if (gpw == full) k_tree_step<GT, BS, full><<<grid, blk, 0, st>>>(d, mode, clear_count, r);
+            else if (gpw == full / 2) k_tree_step<GT, BS, full / 2><<<grid, blk, 0, st>>>(d, mode, clear_count, r);
+            else if (full / 4 >= 1 && gpw == full / 4) k_tree_step<GT, BS, (full / 4 >= 1 ? full / 4 : 1)><<<grid, blk, 0, st>>>(d, mode, clear_count, r);
+            else k_tree_step<GT, BS, 1><<<grid, blk, 0, st>>>(d, mode, clear_count, r);
         }
     });
     AZ_HIP(hipGetLastError());

@@ -21,7 +21,7 @@ MOVES = {"first_max": MOVE_FIRST_MAX, "sample": MOVE_SAMPLE}
 class SelfPlayEngine:
     def __init__(self, game="Connect4", n_games=1, n_playout=500, c_puct=1.25, evaluator="uniform", eval_seed=0,
                  flip="never", reuse_tree=True, dirichlet_alpha=None, rng_seed=0, move="first_max", device=0,
-                 max_plies=0, nodes_per_game=0, game_id_base=0, n_cohorts=0, game_id_stride=1):
+                 max_plies=0, nodes_per_game=0, game_id_base=0, n_cohorts=0, game_id_stride=1, eval_cache=0):
         _abi.require_gpu()
         self.game = GAME_IDS.get(game, game)
         self.L = lib()
@@ -39,6 +39,9 @@ class SelfPlayEngine:
         cfg.max_plies, cfg.nodes_per_game, cfg.game_id_base = int(max_plies), int(nodes_per_game), int(game_id_base)
         cfg.n_cohorts = int(n_cohorts)
         cfg.game_id_stride = int(game_id_stride)
+        # evaluation cache of AZ_EVAL_CNN engines (include/azamd.h: az_config.eval_cache_entries): 0 / True = auto size,
+        # False / negative = off, n > 0 = that many entries
+        cfg.eval_cache_entries = 0 if eval_cache is True else (-1 if eval_cache is False else int(eval_cache))
         self.cfg = cfg
         self.n_playout = int(n_playout)
         h = C.c_void_p()
@@ -47,6 +50,7 @@ class SelfPlayEngine:
         self._keep = None
         check(self.L.az_get_config(self.h, C.byref(cfg)))   # resolved values of the 0 = auto fields
         self.n_cohorts, self.nodes_per_game = int(cfg.n_cohorts), int(cfg.nodes_per_game)
+        self.eval_cache_entries = int(cfg.eval_cache_entries)   # -1: no cache
 
     def close(self):
         if getattr(self, "h", None):

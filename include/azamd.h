@@ -51,7 +51,7 @@ extern "C" {
 #define AZ_MOVE_FIRST_MAX 0 /* parity: first maximum of the sampling distribution, insertion order       */
 #define AZ_MOVE_SAMPLE 1    /* production: sample (player.py:106-111)                                     */
 
-#define AZ_MAX_COHORTS 4
+#define AZ_MAX_COHORTS 8
 
 #define AZ_OK 0
 #define AZ_ERR_ARG (-1)
@@ -88,18 +88,27 @@ typedef struct az_config {
     uint64_t game_id_stride; /* the k-th game this engine starts (slots first, then refills) has the global id      */
                             /* game_id_base + game_id_stride * k; 0 = 1.  Multi-GPU: base = rank, stride = world size, */
                             /* so the ids 0..M-1 of a job's first M games are the same however the job is split.      */
+    int64_t eval_cache_entries; /* AZ_EVAL_CNN: entries (64 B each, rounded up to a power of two) of the evaluation cache, a     */
+                            /* device table shared by all the games of the engine that answers a leaf whose position the     */
+                            /* network has already evaluated with the stored probs and value -- the very bits K3 delivers   */
+                            /* (CNN.predict is a pure function of the position, Network.py:78-85), so every game's           */
+                            /* trajectory is the same with the cache on or off; the reference evaluates every leaf anew      */
+                            /* (MCTS.py:146).  0 = auto (32 Ki entries per slot, 2^16 .. 2^26), < 0 = off.  az_net_load       */
+                            /* empties it.  az_get_config reports the size in use (-1: none).                                 */
 } az_config;
 
 typedef struct az_stats {
     int64_t playouts;      /* playouts executed                                                           */
     int64_t levels;        /* tree levels walked by select (sum of depths)                                */
-    int64_t leaf_evals;    /* non-terminal leaves evaluated                                               */
+    int64_t leaf_evals;    /* non-terminal leaves the evaluator (K3 / host / synthetic) evaluated          */
     int64_t terminal_hits; /* playouts that ended on a terminal node                                      */
     int64_t children;      /* child records written by expansion                                          */
     int64_t nodes_used;    /* sum over games of arena nodes in use                                        */
     int64_t games_finished;
     int64_t plies;
     int64_t rollout_plies; /* moves played inside rollouts (AZ_EVAL_ROLLOUT*)                             */
+    int64_t cache_hits;    /* non-terminal leaves answered by the evaluation cache instead of the network;  */
+                           /* leaf_evals + cache_hits + terminal_hits == playouts                           */
 } az_stats;
 
 const char *az_last_error(void);

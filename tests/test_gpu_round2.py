@@ -292,7 +292,7 @@ def test_cfg3_shape_16384_slots_rccl_gather_store_many(E, blob):
     node pool, 4 cohorts), then finished trajectories packed -> gathered over RCCL (torch.distributed backend "nccl", a
     group of this one rank, collectives forced) -> expanded by store_many into reference-shaped replay tensors.
     Size-independent properties: root N = S and sum(child N) = S - 1 for every slot, identical positions -> identical
-    trees, leaf_evals + terminal_hits = playouts, overflow flags clean, gathered records == packed records, every
+    trees, leaf_evals + cache_hits + terminal_hits = playouts, overflow flags clean, gathered records == packed records, every
     stored game a whole game."""
     import torch
     import torch.distributed as dist
@@ -323,7 +323,7 @@ def test_cfg3_shape_16384_slots_rccl_gather_store_many(E, blob):
             assert (rc[k][par::2] == rc[k][par]).all(), k
         assert (rc["q"][par::2].view(np.uint32) == rc["q"][par].view(np.uint32)).all()
     st = eng.stats()
-    assert st["playouts"] == Gn * S and st["leaf_evals"] + st["terminal_hits"] == st["playouts"]
+    assert st["playouts"] == Gn * S and st["leaf_evals"] + st["cache_hits"] + st["terminal_hits"] == st["playouts"]
     # rolling self-play from these roots until every slot's first game is over (a handful of plies), refill on
     eng.set_roots(roots)
     for _ in range(14):

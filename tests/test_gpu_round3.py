@@ -131,9 +131,11 @@ def test_rolling_equals_lockstep_at_bench_shape(E, blob):
     tr, sr = run(True)
     assert sorted(by_game(tl)) == list(range(N))
     assert_same_games(tl, tr)
-    for k in ("playouts", "leaf_evals", "terminal_hits", "plies", "games_finished", "levels", "children"):
+    for k in ("playouts", "terminal_hits", "plies", "games_finished", "levels", "children"):
         assert sl[k] == sr[k], (k, sl[k], sr[k])
-    assert sl["leaf_evals"] + sl["terminal_hits"] == sl["playouts"] == sl["plies"] * S
+    for st in (sl, sr):
+        assert st["leaf_evals"] + st["cache_hits"] + st["terminal_hits"] == st["playouts"] == st["plies"] * S
+    print("network evaluations lockstep %d rolling %d, cache hits %d / %d" % (sl["leaf_evals"], sr["leaf_evals"], sl["cache_hits"], sr["cache_hits"]))
 
 
 # ------------------------------------------------------------------------------------------------ parking
@@ -234,3 +236,83 @@ def test_fused_search_covers_every_game_for_any_gpw():
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AZ_TREE_GPW=str(gpw)),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert p.returncode == 0, (gpw, p.stderr.decode()[-1500:])
+
+
+# ------------------------------------------------------------------------------------------------ evaluation cache
+@pytest.mark.parametrize("rolling", [True, False])
+@pytest.mark.parametrize("noise", [0.0, 0.7])
+def test_evaluation_cache_changes_nothing_but_the_work(E, blob, rolling, noise):
+    """az_config.eval_cache_entries: a leaf whose position the network has already evaluated is answered from the table with
+    the bits K3 delivers, so a job's games are the same bit for bit with the cache off, on at its default size, and on with a
+    table so small (256 entries) that entries are overwritten all the time; only leaf_evals moves to cache_hits."""
+    Gn, S, N = 96, 40, 192
+    out = {}
+    for name, cache in (("off", False), ("auto", 0), ("tiny", 256)):
+        eng = E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
+                               reuse_tree=True, dirichlet_alpha=noise, rng_seed=41, move="sample", n_cohorts=3, eval_cache=cache)
+        assert eng.eval_cache_entries == {"off": -1, "auto": 1 << 22, "tiny": 256}[name]     # 96 x 32 Ki rounded up to a power of two
+        eng.load_net(blob)
+        n = (eng.selfplay_rolling if rolling else eng.selfplay)(N, temp=1.0, first_n_steps=6)
+        assert n == N
+        out[name] = (eng.traj_fetch(), eng.stats())
+        eng.close()
+    t0, s0 = out["off"]
+    assert s0["cache_hits"] == 0 and s0["leaf_evals"] + s0["terminal_hits"] == s0["playouts"]
+    for name in ("auto", "tiny"):
+        t, s = out[name]
+        assert_same_games(t0, t)
+        for k in ("playouts", "terminal_hits", "plies", "games_finished", "levels", "children"):
+            assert s[k] == s0[k], (name, k)
+        assert s["leaf_evals"] + s["cache_hits"] == s0["leaf_evals"] and s["cache_hits"] > 0, name
+    assert out["auto"][1]["cache_hits"] > out["tiny"][1]["cache_hits"] > 0
+    assert out["auto"][1]["cache_hits"] > 0.3 * s0["leaf_evals"]        # games from one network share their openings
+    print("leaf evaluations without cache %d; cache hits auto %d, 256 entries %d"
+          % (s0["leaf_evals"], out["auto"][1]["cache_hits"], out["tiny"][1]["cache_hits"]))
+
+
+def test_evaluation_cache_is_emptied_by_a_hot_reload(E, blob):
+    """Pipeline.py:87: after az_net_load on a live engine no leaf may be answered with the previous weights' output.  An engine
+    that has filled its cache under checkpoint A and is then given checkpoint B must search exactly like a cache-less engine
+    that only ever saw B (same roots, same recorded flips), and again like A's after reloading A."""
+    blob_b = np.fromfile(os.path.join(G, "weights", "AZ2_Connect4_CNN_best.f32"), dtype="<f4")
+    Gn, S = 64, 60
+    rng = np.random.default_rng(9)
+    flips = rng.integers(0, 2, size=(Gn, S * 2)).astype(np.uint8)
+
+    def searched(eng):
+        eng.reset_games()
+        eng.set_flip_stream(flips)
+        res = []
+        for _ in range(2):
+            eng.search()
+            rc = eng.root_children()
+            a, _ = eng.choose_moves(temp=0.0)
+            res.append((rc["actions"].copy(), rc["visits"].copy(), rc["q"].view(np.uint32).copy(),
+                        rc["prior"].view(np.uint32).copy(), a.copy()))
+            eng.advance(a)
+        return res
+
+    def same(x, y):
+        return all(np.array_equal(u, v) for p, q in zip(x, y) for u, v in zip(p, q))
+
+    mk = lambda cache: E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="stream",
+                                        reuse_tree=True, move="first_max", eval_cache=cache)
+    plain = mk(False)
+    plain.load_net(blob)
+    ref_a = searched(plain)
+    plain.load_net(blob_b)
+    ref_b = searched(plain)
+    plain.close()
+    assert not same(ref_a, ref_b)
+    eng = mk(0)
+    eng.load_net(blob)
+    assert same(searched(eng), ref_a)
+    assert same(searched(eng), ref_a) and eng.stats()["cache_hits"] > Gn * S      # second pass: nearly every leaf is a hit
+    eng.load_net(blob_b)
+    h0 = eng.stats()["cache_hits"]
+    assert same(searched(eng), ref_b)
+    # identical games: only the first one to reach a position misses; none of A's entries may answer
+    eng.load_net(blob)
+    assert same(searched(eng), ref_a)
+    assert eng.stats()["cache_hits"] > h0
+    eng.close()

@@ -78,7 +78,7 @@ def bench_k1(args):
                                    "frac": gbs / HBM_PEAK_GBS}}), flush=True)
 
 
-def bench_tree(game, G, S, c_puct, evaluator, plies, first_n, label):
+def bench_tree(game, G, S, c_puct, evaluator, plies, first_n, label, mean_len=0.0):
     from alphazero_amd.engine import SelfPlayEngine
     eng = SelfPlayEngine(game, n_games=G, n_playout=S, c_puct=c_puct, evaluator=evaluator, eval_seed=7,
                          flip="never" if evaluator == "uniform" else "random", reuse_tree=True, move="sample",
@@ -100,12 +100,13 @@ def bench_tree(game, G, S, c_puct, evaluator, plies, first_n, label):
     fused_ms = prof["fused"]["ms"]
     by, k = tree_bytes(st)
     gbs = by / (fused_ms * 1e-3) / 1e9
-    # plies per finished game from a complete cohort
-    eng.traj_fetch(clear=True)
-    cohort = min(G, 1024)
-    eng.selfplay(cohort, temp=1.0, first_n_steps=first_n)
-    cg, cp = eng.traj_count()
-    mean_len = cp / cg
+    # plies per finished game from a complete cohort (or given: the GPW sweeps time the search launches only)
+    if mean_len <= 0:
+        eng.traj_fetch(clear=True)
+        cohort = min(G, 1024)
+        eng.selfplay(cohort, temp=1.0, first_n_steps=first_n)
+        cg, cp = eng.traj_count()
+        mean_len = cp / cg
     out = {"bench": label, "kernel": "k_search_fused<%s>" % game, "games": G, "playouts_per_move": S,
            "evaluator": evaluator, "plies_timed": plies, "wall_s": dt, "playouts_per_s": st["playouts"] / dt,
            "games_per_s": (st["plies"] / dt) / mean_len, "mean_plies_per_game": mean_len,
@@ -123,7 +124,7 @@ def bench_pure(args):
     """the Elo arena's opponent, pure MCTS (UCT + random rollouts), MCTSPlayer(1, 1000) of
     Pipeline.py:130 for 4096 Connect4 games at once; beside it bench.py's cpu_baseline leg for this search (C port, 1 core)."""
     from alphazero_amd.engine import SelfPlayEngine
-    G, S = 4096, 1000
+    G, S = args.pure_games, 1000
     eng = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.0, evaluator="rollout", flip="random",
                          reuse_tree=False, move="sample", rng_seed=3)
     eng.search()
@@ -138,13 +139,13 @@ def bench_pure(args):
     dt = time.perf_counter() - t0
     st, prof = eng.stats(), eng.get_profile()
     from bench import cpu_baseline_pure   # the CPU port is timed by bench.py's cpu_baseline leg, nowhere else
-    print(json.dumps({"bench": "pure_mcts_c4_4096x1000", "kernel": "k_search_pure<C4>", "games": G,
+    print(json.dumps({"bench": "pure_mcts_c4_%dx1000" % G, "kernel": "k_search_pure<C4>", "games": G,
                       "playouts_per_move": S, "wall_s": dt, "playouts_per_s": st["playouts"] / dt,
                       "rollout_plies_per_s": st["rollout_plies"] / dt,
                       "mean_rollout_plies": st["rollout_plies"] / max(st["leaf_evals"], 1),
                       "mean_depth": st["levels"] / max(st["playouts"], 1),
                       "avg_launch_ms": prof["fused"]["ms"] / max(prof["fused"]["launches"], 1),
-                      "cpu_baseline": cpu_baseline_pure(S)}), flush=True)
+                      "cpu_baseline": None if args.no_cpu else cpu_baseline_pure(S)}), flush=True)
     eng.close()
 
 
@@ -251,14 +252,18 @@ def main():
     ap.add_argument("--games", type=int, default=16384)
     ap.add_argument("--plies", type=int, default=3)
     ap.add_argument("--nbttt-games", type=int, default=8192)
+    ap.add_argument("--ttt-games", type=int, default=4096)
+    ap.add_argument("--pure-games", type=int, default=4096)
+    ap.add_argument("--mean-len", type=float, default=0.0, help="skip the plies-per-game cohort of ttt / nbttt and use this")
+    ap.add_argument("--no-cpu", action="store_true", help="pure: skip the CPU port's leg")
     args = ap.parse_args()
     for w in args.which:
         if w == "k1":
             bench_k1(args)
         elif w == "ttt":
-            bench_tree("TTT", 4096, 100, 1.0, "uniform", 40, 1, "ttt_4096x100_uniform")
+            bench_tree("TTT", args.ttt_games, 100, 1.0, "uniform", 40, 1, "ttt_%dx100_uniform" % args.ttt_games, args.mean_len)
         elif w == "nbttt":
-            bench_tree("NBTTT", args.nbttt_games, 800, 1.5, "hash", 6, 12, "nbttt_%dx800_hash" % args.nbttt_games)
+            bench_tree("NBTTT", args.nbttt_games, 800, 1.5, "hash", 6, 12, "nbttt_%dx800_hash" % args.nbttt_games, args.mean_len)
         elif w == "c4big":
             bench_c4big(args)
         elif w == "pure":
