@@ -134,10 +134,10 @@ template <int STEP>
 __device__ inline void argmax_step(float& score, int& idx) {
     const float os = as_f(dpp_xchg<STEP>(as_u(score)));
     const int oi = (int)dpp_xchg<STEP>((u32)idx);
-    if (os > score || (os == score && oi < idx)) {
-        score = os;
-        idx = oi;
-    }
+    // `|` and `&`, not `||` and `&&`: three compares and two selects, no branches on the exec mask inside the walk's chain
+    const bool take = (os > score) | ((os == score) & (oi < idx));
+    score = take ? os : score;
+    idx = take ? oi : idx;
 }
 // first maximum over the group (ties -> lowest lane = insertion order, MCTS.py:79-80); every lane gets the result
 template <int LG>
@@ -149,6 +149,18 @@ __device__ inline int group_argmax_first(float score, int gl) {
     argmax_step<2>(score, idx);
     if constexpr (LG == 16) argmax_step<3>(score, idx);
     return idx;
+}
+
+// the value held by the ONE lane of the group for which `mine` is set, in every lane of the group: three (four) DPP steps of
+// an OR butterfly instead of a ds_bpermute round trip through the LDS
+template <int LG>
+__device__ inline u32 group_pick(u32 v, bool mine) {
+    v = mine ? v : 0u;
+    v |= dpp_xchg<0>(v);
+    v |= dpp_xchg<1>(v);
+    v |= dpp_xchg<2>(v);
+    if constexpr (LG == 16) v |= dpp_xchg<3>(v);
+    return v;
 }
 
 template <int LG>
@@ -183,15 +195,14 @@ __device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State&
         u32 k = link_nchild(link), first = link_first(link);
         float2 tb = tab_lookup(d, Np);
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        float score = -INFINITY;
-        if ((u32)gl < k) {
-            rec = nodes[first + gl];  // one coalesced 16-byte load per child lane
-            score = puct_score(rec.x, as_f(rec.y), as_f(rec.z), tb);
-        }
-        int best = group_argmax_first<LG>(score, gl);
-        u32 cN = __shfl(rec.x, best, LG);
-        u32 cQ = __shfl(rec.y, best, LG);
-        u32 cl = __shfl(rec.w, best, LG);
+        if ((u32)gl < k) rec = nodes[first + gl];  // one coalesced 16-byte load per child lane
+        // all four words are needed HERE: left to itself the compiler fetches the prior only once it has seen n != 0 (PUCT
+        // returns +inf before it looks at the prior), i.e. a second memory round trip on every level of the walk
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));
+        const float score = (u32)gl < k ? puct_score(rec.x, as_f(rec.y), as_f(rec.z), tb) : -INFINITY;
+        const int best = group_argmax_first<LG>(score, gl);
+        const bool mine = gl == best;
+        const u32 cN = group_pick<LG>(rec.x, mine), cQ = group_pick<LG>(rec.y, mine), cl = group_pick<LG>(rec.w, mine);
         node = first + (u32)best;
         depth++;
         if (gl == 0) {
