@@ -561,7 +561,9 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     hipError_t he = hipStreamCreate(&e->stream);
     // cohorts only pay off where an evaluator launch sits between select and backup (AZ_EVAL_CNN)
     int C = cfg->n_cohorts;
-    if (C <= 0) C = cfg->evaluator != AZ_EVAL_CNN ? 1 : (G >= 4096 ? 4 : G >= 768 ? 3 : (G >= 512 ? 2 : 1));  // measured: DESIGN.md 5
+    // measured: without the evaluation cache 3 cohorts at 2 048 slots (K3 launches fill the chip), with it 4
+    // (K3 launches are a third of the slots: 1 / 2 / 3 / 4 cohorts -> 1 518 / 1 870 / 2 020 / 2 098 games/s; 6 and 8: 1 927, 1 904)
+    if (C <= 0) C = cfg->evaluator != AZ_EVAL_CNN ? 1 : (G >= (d.cache ? 2048 : 4096) ? 4 : G >= 768 ? 3 : (G >= 512 ? 2 : 1));
     if (C > AZ_MAX_COHORTS) C = AZ_MAX_COHORTS;
     if (cfg->evaluator != AZ_EVAL_CNN || C > G) C = 1;
     e->C = C;

@@ -1079,14 +1079,20 @@ static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_
     if (roll) r = *roll;
     AZ_DISPATCH_GAME(game_of(d), {
         static const char* shape = getenv("AZ_TREE_STEP");   // "big" / "small": measurement hook
-        const bool small = shape ? shape[0] == 's' : d.gn >= AZ_TREE_STEP_SMALL_FROM;
+        // with the evaluation cache a launch runs several playouts per game and K3 launches no longer fill the chip: the big
+        // shape wins at every size (2 048 slots 2 093 : 1 927 games/s, 16 384 slots 4 972 : 4 869)
+        const bool small = shape ? shape[0] == 's' : (!d.cache && d.gn >= AZ_TREE_STEP_SMALL_FROM);
         if (small) {
             constexpr int gpb = 256 / GT::LG;
             k_tree_step_small<GT><<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count, r);
         } else {
             constexpr int BS = AZ_TREE_STEP_BS, full = 64 / GT::LG;
             static const char* genv = getenv("AZ_TREE_STEP_GPW");   // measurement hook: games per wave of the big shape
-            int gpw = genv ? atoi(genv) : full;
+            // default by the size of the launch (Connect4, 4 cohorts, cap 6, games/s with 8 / 4 / 2 / 1 games per wave): 512 games
+            // per launch 2 168 / 2 347 / 2 487 / 2 409; 4 096 games per launch 4 972 / - / 4 037 / -.  A wave runs the union of
+            // its games' paths, so few games per wave finish sooner while the chip has idle SIMDs; a big launch needs them
+            int gpw = genv ? atoi(genv) : (d.gn <= 768 ? full / 4 : (d.gn <= 1536 ? full / 2 : full));
+            if (gpw < 1) gpw = 1;
             gpw = gpw >= full ? full : (gpw >= full / 2 ? full / 2 : (gpw >= full / 4 && full / 4 >= 1 ? full / 4 : 1));
             const int gpb = (BS / 64) * gpw;
             const dim3 grid((d.gn + gpb - 1) / gpb), blk(BS);
@@ -1118,7 +1124,10 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     memset(&r, 0, sizeof(r));
     r.on = 1;
     static const char* cap_env = getenv("AZ_ROLL_CAP");   // tuning hook
-    r.cap = cap_env ? atoi(cap_env) : 3;
+    // in-place playouts per game and round: 3 when only terminal playouts are finished in place (round 2's measurement);
+    // with the evaluation cache most playouts are, and 6 measured best (2 048 slots: cap 4 / 6 / 8 -> 2 411 / 2 494 / 2 447
+    // games/s; 16 384 slots: cap 3 / 6 / 10 -> 4 621 / 4 972 / 5 023)
+    r.cap = cap_env ? atoi(cap_env) : (d.cache ? 6 : 3);
     r.S = S;
     r.first_n = first_n;
     r.move_mode = move_mode;

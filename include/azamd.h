@@ -83,7 +83,7 @@ typedef struct az_config {
     int64_t nodes_per_game; /* arena capacity in nodes; 0 = 1 + A*S*(reuse ? max_plies : 1)               */
     uint64_t game_id_base;  /* global id of the first game (slot 0); keys the RNG streams; see game_id_stride */
     int32_t n_cohorts;      /* AZ_EVAL_CNN: slot ranges searched on their own HIP streams so that one range's  */
-                            /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 4096 slots, 3 from 768, 2 from 512), max 4. */
+                            /* tree kernels overlap the other's CNN launch; 0 = auto (4 from 2048 slots [4096 without the evaluation cache], 3 from 768, 2 from 512), max 8. */
                             /* Results do not depend on it (games are independent).                            */
     uint64_t game_id_stride; /* the k-th game this engine starts (slots first, then refills) has the global id      */
                             /* game_id_base + game_id_stride * k; 0 = 1.  Multi-GPU: base = rank, stride = world size, */

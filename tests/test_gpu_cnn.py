@@ -217,7 +217,7 @@ def test_invariants_full_size_c4_cnn(blob):
     Gn, S = 2048, 500
     eng = SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="never",
                          reuse_tree=True)
-    assert eng.n_cohorts == 3
+    assert eng.n_cohorts == 4
     eng.load_net(blob)
     eng.search()
     rc = eng.root_children()

@@ -119,7 +119,7 @@ def test_rolling_equals_lockstep_at_bench_shape(E, blob):
     def run(rolling):
         eng = E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                                reuse_tree=True, rng_seed=21, move="sample")
-        assert eng.n_cohorts == 3
+        assert eng.n_cohorts == 4
         eng.load_net(blob)
         n = (eng.selfplay_rolling if rolling else eng.selfplay)(N, temp=1.0, first_n_steps=10)
         assert n == N
