@@ -312,6 +312,9 @@ def main(argv=None):
                          "duration: a slot plays ~1.5 plies per step), then until twice as many games have finished as there "
                          "are slots (at most 132 steps); 0 = none (all slots start at ply 0 together); n > 0 = staggered "
                          "start, n steps in all")
+    ap.add_argument("--eval-cache", type=int, default=0,
+                    help="evaluation cache of the CNN engines (include/azamd.h: az_config.eval_cache_entries): 0 = the library's "
+                         "default (on, auto size), -1 = off, n = that many entries")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks as child processes of this one even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--workload", choices=["selfplay", "stub"], default="selfplay", help=argparse.SUPPRESS)
@@ -363,7 +366,7 @@ def main(argv=None):
                                   move="sample", rng_seed=0, device=local, game_id_base=rank, game_id_stride=world)
         e = SelfPlayEngine("Connect4", n_games=G, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                            reuse_tree=True, dirichlet_alpha=0.7, rng_seed=0, move="sample", device=local,
-                           game_id_base=rank, game_id_stride=world,
+                           game_id_base=rank, game_id_stride=world, eval_cache=args.eval_cache,
                            # engine default (3 cohorts at 2 048 slots) suits the product kernel; the fp32 Winograd kernel
                            # (5 positions per workgroup, 3 x longer launches) measured best with 4
                            n_cohorts=args.cohorts or (4 if k3 == "wino" and G >= 2048 else 0))
@@ -413,8 +416,9 @@ def main(argv=None):
         # Every rank runs the same number of steps (they hold collectives).
         pre_steps = 0
         if args.preroll != 0:
-            # mean game duration in steps: rolling Connect4 22 (above); lockstep = one ply per step: Connect4 33, NBTTT 30
-            TG = 22 if args.mode == "rolling" else (30 if nb else 33)
+            # mean game duration in steps: rolling Connect4 22 (above; 8 with the evaluation cache, where a slot gets through
+            # ~4.4 playouts per round); lockstep = one ply per step: Connect4 33, NBTTT 41
+            TG = (22 if args.eval_cache < 0 else 8) if args.mode == "rolling" else (41 if nb else 33)
             T0 = TG if args.preroll < 0 else max(1, min(TG, args.preroll))
             limit = 6 * T0 if args.preroll < 0 else args.preroll
             start_step = np.arange(G) % T0
@@ -444,11 +448,12 @@ def main(argv=None):
         # aggregate over ranks: MAX time, SUM of work
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         work = torch.tensor([st["plies"], st["playouts"], st["games_finished"], st["leaf_evals"], st["levels"],
-                             st["terminal_hits"], st["children"]], dtype=torch.float64, device=dev)
+                             st["terminal_hits"], st["children"], st["cache_hits"]], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(work, op=dist.ReduceOp.SUM)
-        r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term", "children"), [float(x) for x in work.tolist()]))
+        r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term", "children", "hits"),
+                     [float(x) for x in work.tolist()]))
         r.update(dt=float(tmax.item()), prof=prof, stored=sink.total_stored - stored0, pre_steps=pre_steps, k3=k3)
         return r
 
@@ -551,7 +556,13 @@ def main(argv=None):
                                   if args.preroll < 0 else ("none" if args.preroll == 0 else "staggered, fixed length"),
                        "mean_plies_per_game": mean_len,
                        "games_finished_in_window": m["finished"], "slot_plies_in_window": m["plies"],
-                       "leaf_evals": m["evals"], "terminal_hits": m["term"],
+                       # playouts = leaf_evals (the network ran) + eval_cache_hits (the network's stored answer) + terminal_hits
+                       "leaf_evals": m["evals"], "terminal_hits": m["term"], "eval_cache_hits": m["hits"],
+                       "eval_cache_entries_per_gpu": getattr(eng, "eval_cache_entries", -1),
+                       "eval_cache_hit_share_of_nonterminal_leaves": m["hits"] / max(m["hits"] + m["evals"], 1),
+                       "eval_cache": None if nb else "device table keyed by the evaluated position, shared by the games of a GPU; a hit "
+                                     "returns the bits K3 delivers, so the games are identical with it on or off "
+                                     "(tests/test_gpu_round3.py); bench.py --eval-cache -1 switches it off",
                        "mean_tree_depth": m["levels"] / max(m["playouts"], 1),
                        "plies_stored_in_replay": m["stored"],
                        # the reference's Python was timed on configs[0]'s game (Connect4, real net); no NBTTT figure exists
@@ -567,32 +578,40 @@ def main(argv=None):
             if "all_cores" in out["cpu_baseline"]:
                 out["config"]["x_cpu_port_all_cores"] = games_s / out["cpu_baseline"]["all_cores"]["value"]
         if world == 1 and not args.no_second_leg:
-            # the other K3 kernel on the same workload, same pre-roll / warm-up / window -- in a process of its own, started
+            # further legs on the same workload, same pre-roll / warm-up / window -- each in a process of its own, started
             # after this one's engine is gone: a second engine in THIS process gets its cohort streams after torch's and
             # the first engine's and has to share hardware queues (measured: 329 instead of 375 games/s for the fp32 leg)
+            #   second_leg_fp32_winograd   the strictly-fp32 K3 kernel (evaluation cache as in the headline)
+            #   leg_no_eval_cache          the headline kernel with the evaluation cache off: every non-terminal leaf goes
+            #                              through the network, the reference's own amount of network work (MCTS.py:146)
             import subprocess
             other = "wino" if args.k3 == "split" else "split"
             eng.close()
             eng = None
-            cmd = [sys.executable, os.path.abspath(__file__), "--k3", other, "--steps", str(args.steps), "--warmup", str(args.warmup),
-                   "--games", str(G), "--playouts", str(S), "--mode", args.mode, "--preroll", str(args.preroll),
-                   "--cohorts", str(args.cohorts), "--mean-plies", repr(mean_len), "--no-cpu-baseline", "--no-second-leg"]
+            base = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                    "--games", str(G), "--playouts", str(S), "--mode", args.mode, "--preroll", str(args.preroll),
+                    "--cohorts", str(args.cohorts), "--mean-plies", repr(mean_len), "--no-cpu-baseline", "--no-second-leg"]
             env = {k: v for k, v in os.environ.items()
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                 "GROUP_RANK", "ROLE_RANK", "AZ_BENCH_SELF_LAUNCHED")}
-            key = "second_leg_" + ("fp32_winograd" if other == "wino" else "split_f16")
-            try:
-                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
-                x = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
-                out[key] = {"value": x["value"], "unit": "games/s",
-                            "value_steady_state_estimate": x["value_steady_state_estimate"], "sims_per_sec": x["sims_per_sec"],
-                            "steps": x["steps"], "ms_per_step": x["ms_per_step"],
-                            "games_finished_in_window": x["config"]["games_finished_in_window"], "dtype": x["dtype"],
-                            "roofline": x["roofline"], "switch": "bench.py --k3 " + other,
-                            "process": "child of the headline run, started after its engine was closed"}
-            except Exception as ex:   # the headline line must not depend on the informational leg
-                out[key] = {"value": 0.0, "unit": "games/s", "error": "%s: %s" % (type(ex).__name__, ex),
-                            "roofline": {"kernel": K3_INFO[other]["kernel"]}, "switch": "bench.py --k3 " + other}
+            legs = [("second_leg_" + ("fp32_winograd" if other == "wino" else "split_f16"),
+                     ["--k3", other, "--eval-cache", str(args.eval_cache)], "bench.py --k3 " + other)]
+            if args.eval_cache >= 0:
+                legs.append(("leg_no_eval_cache", ["--k3", args.k3, "--eval-cache", "-1"], "bench.py --eval-cache -1"))
+            for key, extra, switch in legs:
+                try:
+                    cp = subprocess.run(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+                    x = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+                    out[key] = {"value": x["value"], "unit": "games/s",
+                                "value_steady_state_estimate": x["value_steady_state_estimate"], "sims_per_sec": x["sims_per_sec"],
+                                "steps": x["steps"], "ms_per_step": x["ms_per_step"],
+                                "games_finished_in_window": x["config"]["games_finished_in_window"],
+                                "leaf_evals": x["config"]["leaf_evals"], "eval_cache_hits": x["config"]["eval_cache_hits"],
+                                "dtype": x["dtype"], "roofline": x["roofline"], "switch": switch,
+                                "process": "child of the headline run, started after its engine was closed"}
+                except Exception as ex:   # the headline line must not depend on the informational legs
+                    out[key] = {"value": 0.0, "unit": "games/s", "error": "%s: %s" % (type(ex).__name__, ex),
+                                "roofline": {"kernel": K3_INFO[extra[1]]["kernel"]}, "switch": switch}
         print(json.dumps(out), flush=True)
     if eng is not None:
         eng.close()

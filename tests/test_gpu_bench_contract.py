@@ -35,3 +35,26 @@ def test_bench_line_has_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "games/s" and c["sample"]
     assert d["config"]["plies_stored_in_replay"] > 0 and d["config"]["leaf_evals"] > 0
+    # the evaluation cache is on in the headline and its work is accounted for; the leg without it evaluates every leaf
+    k = d["config"]
+    assert k["eval_cache_hits"] > 0 and 0 < k["eval_cache_hit_share_of_nonterminal_leaves"] < 1 and k["eval_cache_entries_per_gpu"] > 0
+    off = d["leg_no_eval_cache"]
+    assert off["value"] > 0 and off["eval_cache_hits"] == 0 and off["leaf_evals"] > 0
+
+
+def test_bench_config4_line():
+    """bench.py --config 4 (BASELINE configs[4]: NBTTT, fused tree search) at a size the suite can afford: an HBM-class roofline
+    object for k_search_fused<NBTTT> and a cpu_baseline from the C port on the same game and evaluator."""
+    import bench
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        bench.main(["--gpus", "1", "--config", "4", "--steps", "12", "--warmup", "2", "--games", "512", "--playouts", "100",
+                    "--cohort", "128", "--cpu-budget", "1.0", "--preroll", "8"])
+    d = json.loads([l for l in out.getvalue().splitlines() if l.startswith("{")][0])
+    assert d["metric"] == "selfplay_games_per_sec" and d["value"] > 0 and d["config"]["baseline_config"] == 4
+    assert "NBTTT" in d["config"]["workload"] and "configs[4]" in d["config"]["workload"] and d["config"]["mode"] == "lockstep"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_search_fused<NBTTT>"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and r["launches"] == 12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "NBTTT" in d["cpu_baseline"]["sample"]
+    assert d["config"]["plies_stored_in_replay"] > 0
