@@ -69,11 +69,11 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF d
 # roofline.peak stays the data-sheet figure; the measured ceiling is reported beside it.
 SUSTAINED_F16_MFMA_TFLOPS_REAL_DATA = 1340.0
 SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi)
-# HBM bytes per launch of the split kernel in THIS workload (PMC passes on bench.py itself, profiles/r02_k3_pmc.txt:
-# FETCH_SIZE 8271.7 KB x 2 + WRITE_SIZE 18.1 KB): the 2.0 MB of split weights once per XCD L2 per launch; positions in
-# and outputs out are ~25 KB of it
-K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8271.7 + 18.1) * 1024
-K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r02_k3_pmc.txt"
+# HBM bytes per launch of the split kernel in THIS workload (PMC passes on bench.py itself, profiles/r03_k3_pmc.txt:
+# FETCH_SIZE 8079.5 KB x 2 + WRITE_SIZE 17.7 KB; round 2, without the evaluation cache: 8271.7 KB x 2 + 18.1 KB): the 2.0 MB of
+# split weights once per XCD L2 per launch, whatever the launch's size; positions in and outputs out are ~12 KB of it
+K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8079.5 + 17.7) * 1024
+K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r03_k3_pmc.txt"
 DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per k_search_fused<NBTTT> launch at 16 384 games x 800 playouts from the PMC passes of tools/gpu_profile_r03.sh
