@@ -1021,17 +1021,24 @@ static inline int game_of(const Dev& d) { return d.game; }
 // games per wave of the fused searches (a game is touched only by its own lane group, so results do not depend on it).
 // Always a power of two that one of the instantiated kernels has (8 / 4 / 2 / 1), so the grid computed from it matches the
 // kernel that is launched; AZ_TREE_GPW overrides the default (measurement hook) and is rounded DOWN to such a value.
-#ifndef AZ_TREE_GPW_FULL_FROM
-#define AZ_TREE_GPW_FULL_FROM 0x7fffffff   // games per launch from which full waves are used (see the table in pick_gpw)
-#endif
+// Default by regime (round 3, tools/gpw_sweep.sh, profiles/r03_tree_env_pmc.txt; launch time in ms, full / half / quarter waves):
+//   TicTacToe x 100      4 096 games 0.366 / 0.380 / 0.492    16 384: 0.578 / 0.921 / 1.448    65 536: 1.877 / 3.044 / 4.996
+//   NBTTT x 800          4 096 games 5.25 / 4.33 / 5.46        8 192: 6.62 / 5.96 / 9.63        16 384: 10.54 / 10.74 / 17.5
+//   pure MCTS C4 x 1 000 4 096 games 26.1 / 22.9 / 22.7                                         16 384: 31.3 / 40.5 / 58.6
+// Below a few thousand games a launch lasts as long as one game's dependent chain and a wave as long as its slowest game:
+// half-filled waves idle less behind the deepest walk / longest rollout.  Once the chip's issue slots are full (the launch
+// time grows with the number of games) every extra wave costs its share of them and full waves win -- by 1.6 x where all
+// games look alike (TicTacToe with uniform priors), by 7 % where they diverge (NBTTT).  The switch-over sits where the
+// measured curves cross.
+template <class GT>
+static int gpw_full_from() {
+    return GT::GAME == AZ_GAME_TTT ? 4096 : (GT::GAME == AZ_GAME_NBTTT ? 12288 : 8192);
+}
 template <class GT>
 static int pick_gpw(const Dev& d) {
     constexpr int full = 64 / GT::LG;
     static const char* env = getenv("AZ_TREE_GPW");
-    // default: half-filled waves.  A wave lasts as long as its slowest game, and with fewer games per wave less of it idles
-    // behind the deepest walk / longest rollout (measured, full -> half -> quarter: NBTTT 8 192 x 800 7.24 / 6.31 / 10.7 ms,
-    // pure MCTS 4 096 x 1 000 26.2 / 22.9 / 22.8 ms, TicTacToe 4 096 x 100 0.428 / 0.433 / 0.519 ms)
-    int gpw = env ? atoi(env) : (d.G >= AZ_TREE_GPW_FULL_FROM ? full : full / 2);
+    int gpw = env ? atoi(env) : (d.G >= gpw_full_from<GT>() ? full : full / 2);
     if (gpw < 1) gpw = 1;
     if (gpw > full) gpw = full;
     while (gpw & (gpw - 1)) gpw &= gpw - 1;   // round down to a power of two

@@ -78,8 +78,9 @@ DEFAULT_K3 = "split"             # the headline kernel = the library's product k
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per k_search_fused<NBTTT> launch at 16 384 games x 800 playouts from the PMC passes of tools/gpu_profile_r03.sh
 # (profiles/r03_tree_env_pmc.txt); None until measured for the shape in use
-CFG4_TRAFFIC_BYTES_PER_LAUNCH = None
-CFG4_TRAFFIC_SOURCE = None
+CFG4_TRAFFIC_BYTES_PER_LAUNCH = (2 * 742.6 + 3142.4) * 2**20   # FETCH_SIZE x 2 (16-byte-per-lane node reads) + WRITE_SIZE
+CFG4_TRAFFIC_SOURCE = ("rocprofv3 PMC passes on bench.py --config 4 at 16 384 games x 800 playouts, profiles/r03_cfg4_pmc.txt; about half "
+                       "of the algorithmic bytes: the upper tree levels are read from cache")
 REF_PY_GAMES_PER_S = 0.0243      # BASELINE.md section 2 (reference Python, 1 thread, build container) -- not measured here
 
 
@@ -467,7 +468,8 @@ def main(argv=None):
         by = (m["levels"] * (16.0 * k + 8.0) + (m["levels"] + m["playouts"]) * 8.0 + m["children"] * 16.0 + m["evals"] * 4.0) / world
         gbs = by / (max(f["ms"], 1e-9) * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "k_search_fused<NBTTT>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": CFG4_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": CFG4_TRAFFIC_SOURCE,
+                "frac": gbs / HBM_PEAK_GBS,
+                "traffic": CFG4_TRAFFIC_BYTES_PER_LAUNCH if (G, S) == (16384, 800) else None, "traffic_source": CFG4_TRAFFIC_SOURCE,
                 "avg_launch_ms": f["ms"] / max(f["launches"], 1), "launches": f["launches"],
                 "algorithmic_bytes_per_launch": by / max(f["launches"], 1),
                 "bytes_per_playout": by * world / max(m["playouts"], 1), "mean_children": k,
