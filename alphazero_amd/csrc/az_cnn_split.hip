@@ -51,6 +51,9 @@ struct CnnSDev {
     const f16x8* w3[3];    // 36 slices = tap * 4 + cs
     const f16x8* w1[3];    // 4 slices = cs
     const f16x8* w_head;   // [4 cs][hi|lo][64] : rows 0-2 policy conv, 3 value conv
+    // the same tile weights as 16x16x32 fragments (k_cnn_forward_split16): [slice][8 F][hi|lo][64 lanes] f16x8, lane = (channel
+    // 16 F + lane % 16, k = channel 32 cs + 8 (lane / 16) + i)
+    const f16x8 *w16_stem, *w16_3[3], *w16_1[3];
     const float *b_stem, *b3[3], *b1[3], *b_head, *plin_w, *plin_b, *vlin_w, *vlin_b;
     float inv_stem, inv3[3], inv1[3], inv_head;
 };
@@ -635,6 +638,370 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     STAMP(31);   // this wave's end
 }
 
+// ------------------------------------------------------------------------------------------------ 16x16x32 form
+// The product configuration (3 positions per workgroup, 4 waves as a 2 x 2 grid of 64 channels x 64 cells) with the tile loops
+// on v_mfma_f32_16x16x32_f16: 4 x 4 fragments of 16 x 16 per wave (the same 64 accumulator registers), one k-step of 32 per
+// 32-channel slice, the same 8 + 8 operand loads per slice.  Built for the A/B that VERDICT round 2 (item 3) asks for
+// (MI355X_MICROARCH.md "DVFS give-back" (7): under the power limit the clock can depend on the MFMA shape); selected with
+// AZ_K3_SPLIT_CFG=316.  Everything outside the tile loops -- image layout, range scaling, heads, outputs -- is the 32x32x16
+// kernel's, re-indexed for the 16 x 16 accumulator (4 consecutive channels of one cell per fragment and lane).
+struct WPre16 {
+    f16x8 h[4], l[4];
+};
+__device__ inline void w_prefetch16(const f16x8* __restrict__ w, int nsl, int lane, int fbase, WPre16& p) {
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, nsl * 16384, 0x00020000);
+    const int wvo = lane * 16 + fbase * 2048;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        p.h[f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, f * 2048, 0));
+        p.l[f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, f * 2048 + 1024, 0));
+    }
+}
+
+template <int TAPS, int PER_TAP, bool LO_INPUT>
+__device__ inline void conv_split16(const f16x8* __restrict__ w, const _Float16* hi, int lo_off, const int (&brow)[4], int lane,
+                                    int fbase, f32x4 (&acc)[4][4], const WPre16& pre) {
+    constexpr int NSL = TAPS * PER_TAP;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, NSL * 16384, 0x00020000);
+    const int wvo = lane * 16 + fbase * 2048;
+    f16x8 ah[2][4], al[2][4], bh[2][4], bl[2][4];
+    auto fetch_at = [&](const int (&bb)[4], int boff, int wso, int b, bool a_from_pre = false) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            if (a_from_pre) {
+                ah[b][f] = pre.h[f];
+                al[b][f] = pre.l[f];
+                continue;
+            }
+            ah[b][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + f * 2048, 0));
+            al[b][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, wso + f * 2048 + 1024, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bh[b][j] = *reinterpret_cast<const f16x8*>(hi + bb[j] + boff);
+            if (LO_INPUT) bl[b][j] = *reinterpret_cast<const f16x8*>(hi + bb[j] + boff + lo_off);
+        }
+    };
+    auto tap_off = [](int tap) { return ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * SRS; };
+    // cell fragment outer, channel fragment inner: consecutive MFMAs share their B operand (tools/ubench/mfma_shape.hip: 19.5
+    // cycles per MFMA in that order against 22 with the A operand shared)
+    auto mfmas = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int f = 0; f < 4; f++) SMFMA16(ah[b][f], bh[b][j], acc[f][j]);
+        if (LO_INPUT) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int f = 0; f < 4; f++) SMFMA16(ah[b][f], bl[b][j], acc[f][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int f = 0; f < 4; f++) SMFMA16(al[b][f], bh[b][j], acc[f][j]);
+    };
+    constexpr int NA = 8, NB = LO_INPUT ? 8 : 4, NM = (LO_INPUT ? 3 : 2) * 16;
+    auto deal = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NA - NB, 0);
+    };
+    if constexpr (TAPS == 9 && PER_TAP == 4) {
+        int bcur[4], bnxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bcur[j] = brow[j] + tap_off(0), bnxt[j] = brow[j] + tap_off(1);
+        fetch_at(bcur, 0, 0, 0, true);
+        int wso = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+            for (int cs = 0; cs < 4; cs++) {
+                if (cs < 3) fetch_at(bcur, (cs + 1) * 32, wso + (cs + 1) * 16384, (cs + 1) & 1);
+                else fetch_at(bnxt, 0, tap < 8 ? wso + 4 * 16384 : wso, 0);
+                mfmas(cs & 1);
+                deal();
+            }
+            wso += 4 * 16384;
+            const int t2 = tap + 2 < 9 ? tap + 2 : 8;
+#pragma unroll
+            for (int j = 0; j < 4; j++) bcur[j] = bnxt[j], bnxt[j] = brow[j] + tap_off(t2);
+        }
+    } else {
+        auto fetch = [&](int sl, int b, bool a_from_pre = false) {
+            const int tap = TAPS == 1 ? 4 : sl / PER_TAP, cs = sl % PER_TAP;
+            int bb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) bb[j] = brow[j] + tap_off(tap);
+            fetch_at(bb, cs * 32, sl * 16384, b, a_from_pre);
+        };
+        fetch(0, 0, true);
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+            if (sl + 1 < NSL) fetch(sl + 1, (sl + 1) & 1);
+            mfmas(sl & 1);
+            if (sl + 1 < NSL) deal();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_cnn_forward_split16(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
+                                                               const u32* __restrict__ list, const u64* __restrict__ states,
+                                                               float* __restrict__ logp, float* __restrict__ logv,
+                                                               float* __restrict__ probs, float* __restrict__ value, u32 max_n) {
+    extern __shared__ _Float16 lds[];
+    constexpr int SNS = 3, SCELLS = 126, SROWS = srows(3);
+    __shared__ float hb[4][SCELLS];
+    __shared__ float s_player[SNS];
+    __shared__ long long s_slot[SNS];
+    __shared__ u32 s_amax[7][SNS];
+    _Float16* hi = lds;
+    _Float16* lo = lds + SROWS * SRS;
+    const i64 s0 = (i64)blockIdx.x * SNS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, g = lane >> 4;
+    const int wa = wave & 1, wb = wave >> 1, fbase = 4 * wa, ch0 = 64 * wa + 4 * g;
+    WPre16 pre;
+    w_prefetch16(w.w16_stem, 9, lane, fbase, pre);
+    const int ps = tid / 42, pq = tid % 42;
+    const bool mine = tid < SCELLS;
+    u32 li = 0u;
+    if (list && mine && s0 + ps < (i64)max_n) li = list[s0 + ps];
+    const i64 n = n_ptr ? (i64)(*n_ptr) : n_host;
+    constexpr int NZ = SROWS * SRS / 4;
+    u32x4* const lds16 = reinterpret_cast<u32x4*>(lds);
+    for (int i = tid; i < NZ / 2; i += 256) lds16[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (s0 >= n) return;
+    const bool have = mine && s0 + ps < n;
+    const i64 myslot = list ? (i64)li : (s0 + ps);
+    u64 w0 = 0, w1 = 0;
+    if (have) {
+        w0 = states[myslot * 2];
+        w1 = states[myslot * 2 + 1];
+    }
+    for (int i = NZ / 2 + tid; i < NZ; i += 256) lds16[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (tid < 7 * SNS) (&s_amax[0][0])[tid] = 0u;
+    __syncthreads();
+    if (have) {   // input planes from bitboards (env.current_state, env_cython.pyx:143-149)
+        const int row = pq / 7, col = pq % 7;
+        const int bit = col * 7 + (5 - row);
+        const float vt = (w1 >> 63) ? -1.f : 1.f;
+        _Float16* p = hi + scell(ps, row, col) * SRS;
+        p[0] = (_Float16)(float)((w0 >> bit) & 1ull);
+        p[1] = (_Float16)(float)((w1 >> bit) & 1ull);
+        p[2] = (_Float16)vt;
+        if (pq == 0) {
+            s_player[ps] = vt;
+            s_slot[ps] = myslot;
+        }
+    }
+    __syncthreads();
+    // fragment (f, j) of wave (wa, wb): channels 64 wa + 16 f .. + 15, cells 64 wb + 16 j .. + 15; accumulator register r of
+    // lane (n16, g) = channel 64 wa + 16 f + 4 g + r of cell 64 wb + 16 j + n16
+    int brow[4], crow[4], cpos[4];
+    bool live[4];
+    float sc[4], isc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int col = wb * 64 + j * 16 + n16;
+        live[j] = col < SCELLS;
+        if (!live[j]) col = 0;
+        const int s = col / 42, p = col % 42;
+        cpos[j] = s;
+        crow[j] = scell(s, p / 7, p % 7) * SRS;
+        brow[j] = crow[j] + 8 * g;
+        sc[j] = 1.f;
+        isc[j] = 1.f;
+    }
+    f32x4 acc[4][4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 bia[4];
+    auto load_bias = [&](const float* bias) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) bia[f] = *reinterpret_cast<const f32x4*>(bias + ch0 + 16 * f);
+    };
+    f32x4 xres[4][4];
+    auto activate = [&](float inv, bool with_res) {
+        f32x2 invj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) invj[j] = (f32x2){inv * isc[j], inv * isc[j]};
+        const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 a2 = {acc[f][j][r], acc[f][j][r + 1]};
+                    f32x2 v = a2 * invj[j] + (f32x2){bia[f][r], bia[f][r + 1]};
+                    if (with_res) v += (f32x2){xres[f][j][r], xres[f][j][r + 1]};
+                    const f32x2 t = v * nl2e;
+                    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + one;
+                    const f32x2 o = v * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    acc[f][j][r] = o[0];
+                    acc[f][j][r + 1] = o[1];
+                }
+    };
+    auto keep = [&]() {
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) xres[f][j] = acc[f][j];
+    };
+    auto to_image = [&](int layer) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float m = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) m = fmaxf(m, fabsf(acc[f][j][r]));
+            if (live[j]) atomicMax(&s_amax[layer][cpos[j]], __float_as_uint(m));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) range_scale(__uint_as_float(s_amax[layer][cpos[j]]), sc[j], isc[j]);
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (live[j]) {
+                    f16x4 oh, ol;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float v = acc[f][j][r] * sc[j];
+                        oh[r] = (_Float16)v;
+                        ol[r] = (_Float16)(v - (float)oh[r]);
+                    }
+                    const int at = crow[j] + ch0 + 16 * f;
+                    *reinterpret_cast<f16x4*>(hi + at) = oh;
+                    *reinterpret_cast<f16x4*>(lo + at) = ol;
+                }
+        __syncthreads();
+    };
+    // ---- stem
+    zero();
+    load_bias(w.b_stem);
+    conv_split16<9, 1, false>(w.w16_stem, hi, SROWS * SRS, brow, lane, fbase, acc, pre);
+    activate(w.inv_stem, false);
+    keep();
+    w_prefetch16(w.w16_3[0], 36, lane, fbase, pre);
+    to_image(0);
+    // ---- 3 residual blocks
+    for (int blk = 0; blk < 3; blk++) {
+        zero();
+        load_bias(w.b3[blk]);
+        conv_split16<9, 4, true>(w.w16_3[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
+        activate(w.inv3[blk], false);
+        w_prefetch16(w.w16_1[blk], 4, lane, fbase, pre);
+        to_image(1 + 2 * blk);
+        zero();
+        load_bias(w.b1[blk]);
+        conv_split16<1, 4, true>(w.w16_1[blk], hi, SROWS * SRS, brow, lane, fbase, acc, pre);
+        activate(w.inv1[blk], true);
+        keep();
+        if (blk < 2) {
+            w_prefetch16(w.w16_3[blk + 1], 36, lane, fbase, pre);
+        } else {
+#pragma unroll
+            for (int cs = 0; cs < 4; cs++) {   // the heads' convolution weights ride in the first-slice registers
+                pre.h[cs] = w.w_head[(size_t)(cs * 2 + 0) * 64 + lane];
+                pre.l[cs] = w.w_head[(size_t)(cs * 2 + 1) * 64 + lane];
+            }
+        }
+        to_image(2 + 2 * blk);
+    }
+    float pw[2][7], vw[3], hbias[4], pbias[7], vbias[3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) hbias[r] = w.b_head[r];
+#pragma unroll
+    for (int a = 0; a < 7; a++) pbias[a] = w.plin_b[a];
+#pragma unroll
+    for (int k = 0; k < 3; k++) vbias[k] = w.vlin_b[k];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 7; a++) pw[i][a] = (wave < SNS && lane + 64 * i < 126) ? w.plin_w[a * 126 + lane + 64 * i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) vw[k] = (wave < SNS && lane < 42) ? w.vlin_w[k * 42 + lane] : 0.f;
+    // ---- heads: the four 16-cell groups of a wave column are dealt to its two waves
+#pragma unroll
+    for (int j0 = 0; j0 < 2; j0++) {
+        const int jj = wa * 2 + j0;
+        int col = wb * 64 + jj * 16 + n16;
+        const bool lv = col < SCELLS;
+        if (!lv) col = 0;
+        const int sp = col / 42, p = col % 42;
+        const int b16 = scell(sp, p / 7, p % 7) * SRS + 8 * g;
+        f32x4 a4 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int cs = 0; cs < 4; cs++) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(hi + b16 + cs * 32);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(lo + b16 + cs * 32);
+            SMFMA16(pre.h[cs], bh, a4);
+            SMFMA16(pre.h[cs], bl, a4);
+            SMFMA16(pre.l[cs], bh, a4);
+        }
+        if (g == 0 && lv) {
+            float hsc, hisc;
+            range_scale(__uint_as_float(s_amax[6][sp]), hsc, hisc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) hb[r][col] = ssilu(a4[r] * (w.inv_head * hisc) + hbias[r]);
+        }
+    }
+    __syncthreads();
+    // ---- Linear + log-softmax + predict(): wave s, position s (as in k_cnn_forward_split)
+    const int s = wave;
+    if (s >= SNS || s0 + s >= n) return;
+    float pl[7], vl[3];
+    {
+        const float x0 = hb[lane / 42][s * 42 + lane % 42];
+        const float x1 = lane + 64 < 126 ? hb[(lane + 64) / 42][s * 42 + (lane + 64) % 42] : 0.f;
+        const float xv = lane < 42 ? hb[3][s * 42 + lane] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 7; a++) pl[a] = swave_sum(x0 * pw[0][a] + x1 * pw[1][a]) + pbias[a];
+#pragma unroll
+        for (int k = 0; k < 3; k++) vl[k] = swave_sum(xv * vw[k]) + vbias[k];
+    }
+    float mx = pl[0];
+#pragma unroll
+    for (int a = 1; a < 7; a++) mx = fmaxf(mx, pl[a]);
+    float se = 0.f;
+#pragma unroll
+    for (int a = 0; a < 7; a++) se += __expf(pl[a] - mx);
+    const float lse = logf(se);
+    const float mv = fmaxf(vl[0], fmaxf(vl[1], vl[2]));
+    const float lsv = logf(__expf(vl[0] - mv) + __expf(vl[1] - mv) + __expf(vl[2] - mv));
+    const i64 slot = s_slot[s];
+    if (lane < 7) {
+        float mine_l = pl[0];
+#pragma unroll
+        for (int a = 1; a < 7; a++) mine_l = lane == a ? pl[a] : mine_l;
+        const float lp = mine_l - mx - lse;
+        if (logp) logp[slot * 7 + lane] = lp;
+        if (probs) probs[slot * 7 + lane] = __expf(lp);
+    } else if (lane >= 8 && lane < 11) {
+        const int k = lane - 8;
+        const float lv = (k == 0 ? vl[0] : (k == 1 ? vl[1] : vl[2])) - mv - lsv;
+        if (logv) logv[slot * 3 + k] = lv;
+    } else if (lane == 16) {
+        const float v0 = __expf(vl[0] - mv - lsv), v1 = __expf(vl[1] - mv - lsv), v2 = __expf(vl[2] - mv - lsv);
+        if (value) value[slot] = (-s_player[s]) * 0.5f * v0 + v1 - v2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 template <class T>
 static int uploads(CnnS* c, const std::vector<T>& v, const T** out) {
@@ -694,6 +1061,12 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
         return ci < 3 ? (double)wt[((size_t)co * 3 + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co) : 0.0;
     }, pk);
     up16(&c->d.w_stem);
+    const float inv_stem16 = pack_split(9 * 8, [&](int fr, int l, int i) {
+        const int tap = fr / 8, f = fr % 8, co = 16 * f + l % 16, ci = 8 * (l / 16) + i;
+        return ci < 3 ? (double)wt[((size_t)co * 3 + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co) : 0.0;
+    }, pk);
+    up16(&c->d.w16_stem);
+    if (rc == AZ_OK && inv_stem16 != c->d.inv_stem) rc = AZ_ERR_STATE;   // same weights, same power-of-two scale
     if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b_stem);
     for (int b = 0; b < 3; b++) {
         wt = br.take((size_t)128 * 128 * 9);
@@ -704,6 +1077,11 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
             return (double)wt[((size_t)co * SCH + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w3[b]);
+        (void)pack_split(36 * 8, [&](int fr, int l, int i) {
+            const int sl = fr / 8, f = fr % 8, tap = sl >> 2, cs = sl & 3, co = 16 * f + l % 16, ci = 32 * cs + 8 * (l / 16) + i;
+            return (double)wt[((size_t)co * SCH + ci) * 9 + tap] * (double)cnn_bn_scale(bn, co);
+        }, pk);
+        up16(&c->d.w16_3[b]);
         if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b3[b]);
         wt = br.take((size_t)128 * 128);
         bn = cnn_take_bn(br, 128);
@@ -713,6 +1091,11 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
             return (double)wt[(size_t)co * SCH + ci] * (double)cnn_bn_scale(bn, co);
         }, pk);
         up16(&c->d.w1[b]);
+        (void)pack_split(4 * 8, [&](int fr, int l, int i) {
+            const int cc = fr / 8, f = fr % 8, co = 16 * f + l % 16, ci = 32 * cc + 8 * (l / 16) + i;
+            return (double)wt[(size_t)co * SCH + ci] * (double)cnn_bn_scale(bn, co);
+        }, pk);
+        up16(&c->d.w16_1[b]);
         if (rc == AZ_OK) rc = uploads(c, bias_of(bn, 128), &c->d.b1[b]);
     }
     const float* pconv = br.take(3 * 128);
@@ -743,6 +1126,8 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
                         hipFuncSetAttribute((const void*)k_cnn_forward_split<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)split_lds(2)) != hipSuccess ||
                         hipFuncSetAttribute((const void*)k_cnn_forward_split<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(3)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split16, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)split_lds(3)) != hipSuccess)) {
         set_error("hipFuncSetAttribute(k_cnn_forward_split, dynamic LDS) failed");
         rc = AZ_ERR_HIP;
@@ -774,7 +1159,9 @@ int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32
     const int kc = cfg ? atoi(cfg) : SPLIT_DEFAULT_CFG;
     static const char* dsy = getenv("AZ_K3_SPLIT_DESYNC");
     const int desync = dsy ? atoi(dsy) : 0;
-    if (kc == 48)
+    if (kc == 316)   // the product configuration on v_mfma_f32_16x16x32_f16 (A/B form)
+        k_cnn_forward_split16<<<dim3((max_n + 2) / 3), dim3(256), split_lds(3), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, max_n);
+    else if (kc == 48)
         k_cnn_forward_split<4, 8><<<dim3((max_n + 3) / 4), dim3(512), split_lds(4), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
     else if (kc == 34)
         k_cnn_forward_split<3, 4><<<dim3((max_n + 2) / 3), dim3(256), split_lds(3), st>>>(c->d, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n);
