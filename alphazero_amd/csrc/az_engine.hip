@@ -62,15 +62,49 @@ static void build_puct_table(double c_init, int c_base, int n, std::vector<float
 }
 
 
+// Device staging of the host-buffer entry points (the K1 batch calls, az_puct_batch, az_net_forward): the drop-in's Env / CNN
+// methods come through here once per reference call (env.valid_move(), net.predict(): env_cython.pyx / Network.py:78-85), and five
+// hipMalloc + hipFree per call were most of their ~150 us.  Small requests are carved out of a grow-only block per host thread
+// and device, kept until the process ends (every such entry point synchronises before it returns, so the next call may reuse
+// the block); requests beyond POOL_MAX bytes per call are allocated and freed as before.
+struct StagePool {
+    static constexpr size_t POOL_MAX = 8u << 20;
+    void* base[64] = {};
+    size_t cap[64] = {};
+    // no destructor: a thread-local's destructor may run after the HIP runtime has shut down; 8 MB per thread and device stay
+    // allocated until the process ends
+};
+static thread_local StagePool g_pool;
+
 struct TmpBufs {
-    std::vector<void*> v;
+    std::vector<void*> v;   // allocations of this call outside the pool
+    size_t used = 0;
+    int dev = -1;
     ~TmpBufs() {
         for (void* p : v) (void)hipFree(p);
     }
     template <class T>
     int get(T** p, size_t n) {
+        const size_t bytes = (n * sizeof(T) + 64 + 255) & ~(size_t)255;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+        if (dev >= 0 && dev < 64 && used + bytes <= StagePool::POOL_MAX) {
+            if (g_pool.cap[dev] == 0) {   // the whole block at once: later requests of this call must not move earlier ones
+                void* q = nullptr;
+                if (hipMalloc(&q, StagePool::POOL_MAX) == hipSuccess) {
+                    g_pool.base[dev] = q;
+                    g_pool.cap[dev] = StagePool::POOL_MAX;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (used + bytes <= g_pool.cap[dev]) {
+                *p = reinterpret_cast<T*>(static_cast<char*>(g_pool.base[dev]) + used);
+                used += bytes;
+                return AZ_OK;
+            }
+        }
         void* q = nullptr;
-        hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+        hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) {
             set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
             return AZ_ERR_HIP;
@@ -78,6 +112,29 @@ struct TmpBufs {
         v.push_back(q);
         *p = (T*)q;
         return AZ_OK;
+    }
+};
+
+// One contiguous device block and its host mirror: the inputs of a host-buffer call go down in ONE hipMemcpy and all its
+// outputs come back in ONE (a drop-in Env method is a single position: five separate 1-to-16-byte copies were ~40 us each).
+struct Block {
+    char* dev = nullptr;
+    std::vector<char> host;
+    size_t size = 0;
+    size_t reserve(size_t bytes) {
+        const size_t o = size;
+        size = (size + bytes + 255) & ~(size_t)255;
+        return o;
+    }
+    int alloc(TmpBufs& t) {
+        host.resize(size);
+        return t.get(&dev, size);
+    }
+    template <class T>
+    T* d(size_t off) { return reinterpret_cast<T*>(dev + off); }
+    void put(size_t off, const void* src, size_t bytes) { memcpy(host.data() + off, src, bytes); }
+    void take(size_t off, void* dst, size_t bytes) {
+        if (dst) memcpy(dst, host.data() + off, bytes);
     }
 };
 
@@ -261,29 +318,24 @@ int az_env_step_batch(int game, int device, int64_t n, const uint64_t* states_in
     AZ_TRY(use_device(device));
     if (n == 0) return AZ_OK;
     TmpBufs t;
-    u64 *din, *dout;
-    i32* dact = nullptr;
-    u8 *dpl, *ddn;
-    i8* dwn;
-    u16* dlg;
-    AZ_TRY(t.get(&din, n * gi.W));
-    AZ_TRY(t.get(&dout, n * gi.W));
-    AZ_TRY(t.get(&dpl, n));
-    AZ_TRY(t.get(&ddn, n));
-    AZ_TRY(t.get(&dwn, n));
-    AZ_TRY(t.get(&dlg, n));
-    AZ_HIP(hipMemcpy(din, states_in, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
-    if (actions) {
-        AZ_TRY(t.get(&dact, n));
-        AZ_HIP(hipMemcpy(dact, actions, n * sizeof(i32), hipMemcpyHostToDevice));
-    }
-    AZ_TRY(launch_env_step(game, n, din, dact, dout, dpl, dwn, ddn, dlg, 0));
-    AZ_HIP(hipDeviceSynchronize());
-    if (states_out) AZ_HIP(hipMemcpy(states_out, dout, n * gi.W * sizeof(u64), hipMemcpyDeviceToHost));
-    if (placed) AZ_HIP(hipMemcpy(placed, dpl, n, hipMemcpyDeviceToHost));
-    if (winner) AZ_HIP(hipMemcpy(winner, dwn, n, hipMemcpyDeviceToHost));
-    if (done) AZ_HIP(hipMemcpy(done, ddn, n, hipMemcpyDeviceToHost));
-    if (legal) AZ_HIP(hipMemcpy(legal, dlg, n * sizeof(u16), hipMemcpyDeviceToHost));
+    Block in, out;
+    const size_t sb = (size_t)n * gi.W * sizeof(u64);
+    const size_t i_st = in.reserve(sb), i_act = actions ? in.reserve((size_t)n * 4) : 0;
+    const size_t o_st = out.reserve(sb), o_pl = out.reserve(n), o_wn = out.reserve(n), o_dn = out.reserve(n),
+                 o_lg = out.reserve((size_t)n * 2);
+    AZ_TRY(in.alloc(t));
+    AZ_TRY(out.alloc(t));
+    in.put(i_st, states_in, sb);
+    if (actions) in.put(i_act, actions, (size_t)n * 4);
+    AZ_HIP(hipMemcpy(in.dev, in.host.data(), in.size, hipMemcpyHostToDevice));
+    AZ_TRY(launch_env_step(game, n, in.d<u64>(i_st), actions ? in.d<i32>(i_act) : nullptr, out.d<u64>(o_st), out.d<u8>(o_pl),
+                           out.d<i8>(o_wn), out.d<u8>(o_dn), out.d<u16>(o_lg), 0));
+    AZ_HIP(hipMemcpy(out.host.data(), out.dev, out.size, hipMemcpyDeviceToHost));   // on the null stream: after the kernel
+    out.take(o_st, states_out, sb);
+    out.take(o_pl, placed, n);
+    out.take(o_wn, winner, n);
+    out.take(o_dn, done, n);
+    out.take(o_lg, legal, (size_t)n * 2);
     return AZ_OK;
 }
 
@@ -297,22 +349,20 @@ int az_env_status_batch(int game, int device, int64_t n, const uint64_t* states,
     AZ_TRY(use_device(device));
     if (n == 0) return AZ_OK;
     TmpBufs t;
-    u64* din;
-    u8 *ddn, *dfl;
-    i8* dwn;
-    u16* dlg;
-    AZ_TRY(t.get(&din, n * gi.W));
-    AZ_TRY(t.get(&ddn, n));
-    AZ_TRY(t.get(&dfl, n));
-    AZ_TRY(t.get(&dwn, n));
-    AZ_TRY(t.get(&dlg, n));
-    AZ_HIP(hipMemcpy(din, states, n * gi.W * sizeof(u64), hipMemcpyHostToDevice));
-    AZ_TRY(launch_env_status(game, n, din, dwn, ddn, dlg, dfl, 0));
-    AZ_HIP(hipDeviceSynchronize());
-    if (winner) AZ_HIP(hipMemcpy(winner, dwn, n, hipMemcpyDeviceToHost));
-    if (done) AZ_HIP(hipMemcpy(done, ddn, n, hipMemcpyDeviceToHost));
-    if (legal) AZ_HIP(hipMemcpy(legal, dlg, n * sizeof(u16), hipMemcpyDeviceToHost));
-    if (full) AZ_HIP(hipMemcpy(full, dfl, n, hipMemcpyDeviceToHost));
+    Block in, out;
+    const size_t sb = (size_t)n * gi.W * sizeof(u64);
+    const size_t i_st = in.reserve(sb);
+    const size_t o_wn = out.reserve(n), o_dn = out.reserve(n), o_lg = out.reserve((size_t)n * 2), o_fl = out.reserve(n);
+    AZ_TRY(in.alloc(t));
+    AZ_TRY(out.alloc(t));
+    in.put(i_st, states, sb);
+    AZ_HIP(hipMemcpy(in.dev, in.host.data(), in.size, hipMemcpyHostToDevice));
+    AZ_TRY(launch_env_status(game, n, in.d<u64>(i_st), out.d<i8>(o_wn), out.d<u8>(o_dn), out.d<u16>(o_lg), out.d<u8>(o_fl), 0));
+    AZ_HIP(hipMemcpy(out.host.data(), out.dev, out.size, hipMemcpyDeviceToHost));
+    out.take(o_wn, winner, n);
+    out.take(o_dn, done, n);
+    out.take(o_lg, legal, (size_t)n * 2);
+    out.take(o_fl, full, n);
     return AZ_OK;
 }
 
@@ -1273,20 +1323,20 @@ int az_net_forward(az_engine* e, int64_t n, const uint64_t* states, float* logp,
     if (n < 0 || !states) return bad_arg("az_net_forward");
     if (n == 0) return AZ_OK;
     TmpBufs t;
+    Block out;
     u64* ds;
-    float *dlp, *dlv, *dp, *dv;
     AZ_TRY(t.get(&ds, n * 2));
-    AZ_TRY(t.get(&dlp, n * 7));
-    AZ_TRY(t.get(&dlv, n * 3));
-    AZ_TRY(t.get(&dp, n * 7));
-    AZ_TRY(t.get(&dv, n));
-    AZ_HIP(hipMemcpy(ds, states, n * 16, hipMemcpyHostToDevice));
-    AZ_TRY(cnn_forward(e->net, n, ds, dlp, dlv, dp, dv, e->stream));
+    const size_t o_lp = out.reserve((size_t)n * 28), o_lv = out.reserve((size_t)n * 12), o_p = out.reserve((size_t)n * 28),
+                 o_v = out.reserve((size_t)n * 4);
+    AZ_TRY(out.alloc(t));
+    AZ_HIP(hipMemcpyAsync(ds, states, n * 16, hipMemcpyHostToDevice, e->stream));
+    AZ_TRY(cnn_forward(e->net, n, ds, out.d<float>(o_lp), out.d<float>(o_lv), out.d<float>(o_p), out.d<float>(o_v), e->stream));
+    AZ_HIP(hipMemcpyAsync(out.host.data(), out.dev, out.size, hipMemcpyDeviceToHost, e->stream));   // all four outputs at once
     AZ_HIP(hipStreamSynchronize(e->stream));
-    if (logp) AZ_HIP(hipMemcpy(logp, dlp, n * 28, hipMemcpyDeviceToHost));
-    if (logv) AZ_HIP(hipMemcpy(logv, dlv, n * 12, hipMemcpyDeviceToHost));
-    if (probs) AZ_HIP(hipMemcpy(probs, dp, n * 28, hipMemcpyDeviceToHost));
-    if (value) AZ_HIP(hipMemcpy(value, dv, n * 4, hipMemcpyDeviceToHost));
+    out.take(o_lp, logp, (size_t)n * 28);
+    out.take(o_lv, logv, (size_t)n * 12);
+    out.take(o_p, probs, (size_t)n * 28);
+    out.take(o_v, value, (size_t)n * 4);
     return AZ_OK;
 }
 

@@ -25,4 +25,15 @@ for n in (1, 256, 4096, 65536):
         ds = (time.perf_counter() - t0) / reps
         line += " | az_net_forward_static: %9.1f us  %.3e leaves/s" % (ds * 1e6, n / ds)
     print(line)
+from alphazero_amd.engine import env_status_batch, env_step_batch
+one = np.zeros((1, 2), np.uint64)
+calls = (("az_env_status_batch n=1 (env.valid_move / done)", lambda: env_status_batch("Connect4", one)),
+         ("az_env_step_batch   n=1 (env.step)", lambda: env_step_batch("Connect4", one, np.array([3], np.int32))))
+for name, fn in calls + calls:
+    for _ in range(5):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        fn()
+    print("%-52s %7.1f us per call" % (name, (time.perf_counter() - t0) / 200 * 1e6))
 e.close()
