@@ -395,12 +395,15 @@ def test_cfg4_shape_nbttt_deep_trees(E):
 
 
 # ------------------------------------------------------------------------------------------------ bench.py launcher
-def test_bench_starts_its_own_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_bench_starts_its_own_ranks_on_one_gpu(tmp_path, config):
     """`python bench.py --gpus N` outside torchrun starts N ranks itself (fresh child processes, RCCL rendezvous on
     127.0.0.1).  One GPU here, so N = 1 with --launch: the child is rank 0 of a 1-rank RCCL group and walks the barrier /
-    all-reduce / gather code of the N-GPU job; its line must say n_gpus = 1 = the ranks RCCL reports."""
+    all-reduce / gather code of the N-GPU job; its line must say n_gpus = 1 = the ranks RCCL reports.  All three first-class
+    workloads (BASELINE configs[2], [3], [4]) at sizes the suite can afford."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "--steps", "6", "--warmup", "1",
-           "--games", "256", "--playouts", "40", "--cohort", "64", "--no-cpu-baseline", "--no-second-leg", "--preroll", "4"]
+           "--config", str(config), "--games", "256", "--playouts", "40", "--cohort", "64", "--no-cpu-baseline",
+           "--no-second-leg", "--preroll", "4"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -409,3 +412,5 @@ def test_bench_starts_its_own_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] >= 0 and d["config"]["plies_stored_in_replay"] >= 0
     assert d["config"]["launcher"] == "bench.py (self-launched ranks)" and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["baseline_config"] == config and ("configs[%d]" % config) in d["config"]["workload"]
+    assert d["roofline"]["bound"] == ("hbm" if config == 4 else "mfma")
