@@ -74,6 +74,7 @@ SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product
 # split weights once per XCD L2 per launch, whatever the launch's size; positions in and outputs out are ~12 KB of it
 K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8079.5 + 17.7) * 1024
 K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r03_k3_pmc.txt"
+TREE_STEP_TRAFFIC_BYTES_PER_LAUNCH = (2 * 1078.0 + 470.4) * 1024   # same passes: k_tree_step<C4, 512, 2>, 512 games per launch
 DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per k_search_fused<NBTTT> launch at 16 384 games x 800 playouts from the PMC passes of tools/gpu_profile_r03.sh
@@ -434,8 +435,9 @@ def main(argv=None):
         for _ in range(warmup):
             one_step()
         eng.reset_stats()
-        # 2: HIP events around the K3 launches only; the fused-search workload has one launch per step: time them all
-        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all or nb else 2))
+        # the fused-search workload has one launch per step: time them all
+        # CNN workloads: mode 3 = every K3 launch + every fourth tree-step launch of the first cohort (a sample for roofline_tree_step)
+        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all or nb else int(os.environ.get("AZ_BENCH_PROF", "3"))))
         stored0 = sink.total_stored
         barrier()
         t0 = time.perf_counter()
@@ -476,6 +478,32 @@ def main(argv=None):
                 "playouts_per_launch": m["playouts"] / world / max(f["launches"], 1),
                 "note": "pointer chase over per-game arenas: the launch is bound by issue slots / dependent-load latency, not "
                         "HBM (DESIGN.md 4.1); algorithmic bytes priced against the HBM peak as SURVEY 8d asks"}
+
+    def roofline_tree_step(m):
+        """The other kernel of a CNN-workload round, k_tree_step (backup of the evaluated playout, ply ends, up to 1 + cap walks
+        with cache probes): HBM class by SURVEY 8d's definition, latency-bound in fact.  Algorithmic bytes from
+        the run's counters: select levels x (16 k + 8), backup (levels + playouts) x 8, expand children x 16 + 4 per
+        expansion, one 64-byte cache probe per non-terminal playout and one 64-byte insert per network evaluation; duration
+        = HIP events around every fourth launch of the first cohort (a sample: 1 in 4 n_cohorts)."""
+        b = m["prof"]["backup"]
+        if not b["launches"]:
+            return None
+        nonterm = m["evals"] + m["hits"]
+        k = m["children"] / max(nonterm, 1)
+        by = (m["levels"] * (16.0 * k + 8.0) + (m["levels"] + m["playouts"]) * 8.0 + m["children"] * 16.0 + nonterm * 4.0
+              + 64.0 * nonterm + 64.0 * m["evals"]) / world
+        launches_all = m["prof"]["cnn"]["launches"]          # one tree step per K3 launch
+        per_launch = by / max(launches_all, 1)
+        avg_ms = b["ms"] / b["launches"]
+        gbs = per_launch / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "k_tree_step<C4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": TREE_STEP_TRAFFIC_BYTES_PER_LAUNCH if (G, S) == (2048, 500) else None,
+                "traffic_source": "rocprofv3 PMC passes on bench.py, profiles/r03_k3_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE)",
+                "avg_launch_ms": avg_ms, "sampled_launches": b["launches"], "launches": launches_all,
+                "algorithmic_bytes_per_launch": per_launch, "playouts_per_launch": m["playouts"] / world / max(launches_all, 1),
+                "bytes_per_playout": by * world / max(m["playouts"], 1),
+                "note": "a launch lasts as long as one game's chain of up to 1 + cap dependent playouts (~14 us each beside K3): "
+                        "latency-bound, the HBM roof is not what limits it"}
 
     def roofline(m, k3):
         if nb:
@@ -570,6 +598,7 @@ def main(argv=None):
                        # the reference's Python was timed on configs[0]'s game (Connect4, real net); no NBTTT figure exists
                        "x_reference_python_1thread": None if nb else games_s / REF_PY_GAMES_PER_S},
             "roofline": roofline(m, args.k3),
+            "roofline_tree_step": None if nb else roofline_tree_step(m),
             "kernel_time_ms": {k: v["ms"] for k, v in m["prof"].items()},
             "box": _box_info(torch, local),
         }

@@ -148,7 +148,8 @@ int az_reset_stats(az_engine *e);
 /* Live kernel timing with HIP events recorded on the engine's own stream around every search kernel launch.
  * Categories: 0 = CNN leaf evaluation (K3), 1 = select (K2), 2 = expand/backup (K2), 3 = fused search (K2).
  * az_get_profile returns accumulated milliseconds and launch counts since az_set_profiling(e, on);
- * on = 1: every category, 2: the CNN launches only (half the events to record and read back), 0: off. */
+ * on = 1: every category, 2: the CNN launches only (half the events to record and read back), 3: the CNN launches and, of
+ * the other categories, every fourth launch of the first cohort only (a sample: 1 in 16 with four cohorts), 0: off. */
 int az_set_profiling(az_engine *e, int on);
 int az_get_profile(az_engine *e, double *ms4, int64_t *launches4);
 /* per category, the time (ms) during which at least one launch of it was executing: the union of the launches'
