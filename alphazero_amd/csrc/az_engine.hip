@@ -590,8 +590,10 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         (void)hipMemcpy(dt64, t64.data(), t64.size() * sizeof(double2), hipMemcpyHostToDevice);
         d.tab64 = dt64;
     }
-    // evaluation cache (az_tree.hip "Evaluation cache"): AZ_EVAL_CNN engines, unless switched off.  Auto size: 32 Ki entries
-    // per slot (a game evaluates ~8 k distinct positions; room for several generations of games), 2^16 .. 2^26 entries of 64 B
+    // evaluation cache (az_tree.hip "Evaluation cache"): AZ_EVAL_CNN engines, unless switched off.  Auto size: 128 Ki entries
+    // (8 MB) per slot, 2^16 .. 2^30 entries of 64 B -- 17 GB for 2 048 slots, 68 GB for 16 384: a game evaluates ~8 k distinct
+    // positions and what pays is the history of MANY generations of games (measured, games/s at 2^26 / 2^28 / 2^30 entries:
+    // 2 048 slots 2 744 / 2 867 / 2 841, 16 384 slots 4 917 / 6 502 / 7 414; 2^31: 7 489); the board has 288 GB
     e->cfg.eval_cache_entries = -1;
     {
         static const char* cenv = getenv("AZ_EVAL_CACHE");   // "0": off whatever the configuration says (A/B runs); "n": 2^n entries
@@ -599,7 +601,7 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         if (cenv && atoi(cenv) == 0) want = -1;
         else if (cenv && atoi(cenv) > 0 && want == 0) want = 1ll << std::min(atoi(cenv), 31);
         if (cfg->evaluator == AZ_EVAL_CNN && want >= 0) {
-            if (want == 0) want = std::min<i64>(std::max<i64>(G * 32768, 1ll << 16), 1ll << 26);
+            if (want == 0) want = std::min<i64>(std::max<i64>(G * 131072, 1ll << 16), 1ll << 30);
             i64 n = 1;
             while (n < want && n < (1ll << 31)) n <<= 1;
             uint4* tab = nullptr;

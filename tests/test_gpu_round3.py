@@ -250,7 +250,7 @@ def test_evaluation_cache_changes_nothing_but_the_work(E, blob, rolling, noise):
     for name, cache in (("off", False), ("auto", 0), ("tiny", 256)):
         eng = E.SelfPlayEngine("Connect4", n_games=Gn, n_playout=S, c_puct=1.25, evaluator="cnn", flip="random",
                                reuse_tree=True, dirichlet_alpha=noise, rng_seed=41, move="sample", n_cohorts=3, eval_cache=cache)
-        assert eng.eval_cache_entries == {"off": -1, "auto": 1 << 22, "tiny": 256}[name]     # 96 x 32 Ki rounded up to a power of two
+        assert eng.eval_cache_entries == {"off": -1, "auto": 1 << 24, "tiny": 256}[name]     # 96 x 128 Ki rounded up to a power of two
         eng.load_net(blob)
         n = (eng.selfplay_rolling if rolling else eng.selfplay)(N, temp=1.0, first_n_steps=6)
         assert n == N
