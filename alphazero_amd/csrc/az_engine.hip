@@ -208,6 +208,8 @@ struct az_engine {
     int prof_on = 0;      // mask of the categories being timed
     bool prof_sample0 = false;   // categories other than the CNN: only every fourth launch on the engine stream (cohort 0)
     unsigned prof_tick = 0;
+    bool prof_blocks = false;    // az_set_profiling(e, 4): only blocks of 64 consecutive rounds out of every 512
+    unsigned prof_round = 0;     // rounds seen (CNN launches on the engine stream)
     bool prof_skip = true;
     std::vector<hipEvent_t> prof_ev;   // pairs: [2i] start, [2i+1] stop
     std::vector<int> prof_cat;
@@ -265,6 +267,19 @@ static int prof_begin(az_engine* e, int cat, hipStream_t st) {
     // event record is a packet of its own in the cohort's queue between two dependent kernels, i.e. a few microseconds on
     // every round's chain: timing every tree step as well cost the bench 3 %; a sample of 1 in 4 n_cohorts does not show.
     if (e->prof_sample0 && cat != PROF_CNN && (st != e->stream || (e->prof_tick++ & 3u))) e->prof_skip = true;
+    // az_set_profiling(e, 4): the event packets sit between dependent kernels of a cohort's chain and cost a bench round 6 us per
+    // gap (profiles/r03_bench_kernel_stats.txt: 213 us per round with events around every K3 launch, 199 us with none).  Mode 4
+    // times blocks of 64 consecutive rounds out of every 512: inside a block every cohort's K3 launch (so that the union of
+    // their intervals means something) and cohort 0's tree step; outside it nothing.  The cohorts' streams drift apart by a
+    // round or two between two synchronisations, so short blocks of different cohorts do not coincide in time and the union
+    // comes out too long: blocks of 16 / 64 / 128 / 256 rounds read K3's rate 9 / 1 / 1 / 1 % below what timing every launch reads.
+    if (e->prof_blocks) {
+        if (cat == PROF_CNN && st == e->stream) e->prof_round++;
+        static const char* benv = getenv("AZ_PROF_BLOCK");   // measurement hook: log2 of the block length (period = 8 blocks)
+        const unsigned lb = benv ? (unsigned)atoi(benv) : 6u;
+        const bool in_block = ((e->prof_round - 1u) & ((8u << lb) - 1u)) < (1u << lb);
+        if (!in_block || (cat != PROF_CNN && st != e->stream)) e->prof_skip = true;
+    }
     if (e->prof_skip) return AZ_OK;
     if (e->prof_used * 2 >= e->prof_ev.size()) {
         int rc = prof_harvest(e);
@@ -736,8 +751,10 @@ int az_set_profiling(az_engine* e, int on) {
         e->prof_cat.resize(pairs);
         for (auto& ev : e->prof_ev) AZ_HIP(hipEventCreate(&ev));
     }
-    e->prof_on = (on == 1 || on == 3) ? 0xF : (on == 2 ? (1 << PROF_CNN) : 0);   // category mask
+    e->prof_on = (on == 1 || on == 3 || on == 4) ? 0xF : (on == 2 ? (1 << PROF_CNN) : 0);   // category mask
     e->prof_sample0 = on == 3;
+    e->prof_blocks = on == 4;
+    e->prof_round = 0;
     for (int i = 0; i < 4; i++) {
         e->prof_ms[i] = 0;
         e->prof_n[i] = 0;

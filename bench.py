@@ -436,8 +436,12 @@ def main(argv=None):
             one_step()
         eng.reset_stats()
         # the fused-search workload has one launch per step: time them all
-        # CNN workloads: mode 3 = every K3 launch + every fourth tree-step launch of the first cohort (a sample for roofline_tree_step)
-        eng.set_profiling(0 if args.no_profile else (1 if args.profile_all or nb else int(os.environ.get("AZ_BENCH_PROF", "3"))))
+        # CNN workloads, rolling: mode 4 = blocks of 64 consecutive rounds out of every 512, inside a block every cohort's K3 launch
+        # and the first cohort's tree step (an event record is a packet between two dependent kernels of a cohort's chain:
+        # events around every K3 launch stretch a 199 us round to 213 us, profiles/r03_bench_kernel_stats.txt).  AZ_BENCH_PROF=3
+        # times every K3 launch + every fourth tree step of the first cohort, =1 everything.
+        pmode = 0 if args.no_profile else (1 if args.profile_all or nb else int(os.environ.get("AZ_BENCH_PROF", "4" if args.mode == "rolling" else "3")))
+        eng.set_profiling(pmode)
         stored0 = sink.total_stored
         barrier()
         t0 = time.perf_counter()
@@ -457,7 +461,10 @@ def main(argv=None):
             dist.all_reduce(work, op=dist.ReduceOp.SUM)
         r = dict(zip(("plies", "playouts", "finished", "evals", "levels", "term", "children", "hits"),
                      [float(x) for x in work.tolist()]))
-        r.update(dt=float(tmax.item()), prof=prof, stored=sink.total_stored - stored0, pre_steps=pre_steps, k3=k3)
+        # K3 launches of this rank in the window (= tree steps): counted by the events unless they only sample (mode 4)
+        launches = steps * S * eng.n_cohorts if pmode == 4 else prof["cnn"]["launches"]
+        r.update(dt=float(tmax.item()), prof=prof, stored=sink.total_stored - stored0, pre_steps=pre_steps, k3=k3, launches=launches,
+                 pmode=pmode)
         return r
 
     def roofline_tree(m):
@@ -484,7 +491,8 @@ def main(argv=None):
         with cache probes): HBM class by SURVEY 8d's definition, latency-bound in fact.  Algorithmic bytes from
         the run's counters: select levels x (16 k + 8), backup (levels + playouts) x 8, expand children x 16 + 4 per
         expansion, one 64-byte cache probe per non-terminal playout and one 64-byte insert per network evaluation; duration
-        = HIP events around every fourth launch of the first cohort (a sample: 1 in 4 n_cohorts)."""
+        = HIP events around a sample of the first cohort's launches (mode 4: those of the timed blocks, 1 in 8 n_cohorts;
+        mode 3: every fourth, 1 in 4 n_cohorts)."""
         b = m["prof"]["backup"]
         if not b["launches"]:
             return None
@@ -492,7 +500,7 @@ def main(argv=None):
         k = m["children"] / max(nonterm, 1)
         by = (m["levels"] * (16.0 * k + 8.0) + (m["levels"] + m["playouts"]) * 8.0 + m["children"] * 16.0 + nonterm * 4.0
               + 64.0 * nonterm + 64.0 * m["evals"]) / world
-        launches_all = m["prof"]["cnn"]["launches"]          # one tree step per K3 launch
+        launches_all = m["launches"]                         # one tree step per K3 launch
         per_launch = by / max(launches_all, 1)
         avg_ms = b["ms"] / b["launches"]
         gbs = per_launch / (avg_ms * 1e-3) / 1e9
@@ -511,12 +519,16 @@ def main(argv=None):
         cnn = m["prof"]["cnn"]
         evals_rank = m["evals"] / world
         cnn_avg_ms = cnn["ms"] / max(cnn["launches"], 1)
-        leaves_per_launch = evals_rank / max(cnn["launches"], 1)
+        leaves_per_launch = evals_rank / max(m["launches"], 1)
+        timed_share = cnn["launches"] / max(m["launches"], 1)   # 1 unless the events sample (mode 4: 64 rounds in 512)
         # K3 launches of different cohorts run concurrently on their own streams, so the time the kernel occupies the
         # GPU is the UNION of the launches' [start, stop] intervals (HIP events on the launch streams), not their sum.
         # achieved = FLOPs of all launches / that busy time  (= FLOPs per launch / avg duration when the launches do
         # not overlap, i.e. --cohorts 1).
-        alg = FLOP_PER_LEAF * evals_rank / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
+        # Sampled (mode 4): the union is taken inside the timed blocks and priced with the blocks' share of the window's leaves;
+        # launches of the neighbouring, untimed rounds that overlap a block's first and last intervals are not counted, which
+        # can only lower `achieved`.
+        alg = FLOP_PER_LEAF * evals_rank * timed_share / (max(cnn["busy_ms"], 1e-9) * 1e-3) / 1e12
         info = K3_INFO[k3]
         if k3 == "split":
             # priced on the pipe it runs on: EXECUTED fp16 MFMA flops (3 per algorithmic flop) against the dense fp16 peak;
@@ -536,7 +548,11 @@ def main(argv=None):
                     "traffic": K3_TRAFFIC_BYTES_PER_LAUNCH, "traffic_source": "rocprofv3 PMC pass, profiles/r01_k3_pmc.txt",
                     "algorithm": info["algorithm"], "executed_flop_per_leaf": EXEC_FLOP_PER_LEAF,
                     "executed_frac": alg * (EXEC_FLOP_PER_LEAF / FLOP_PER_LEAF) / PEAK_F32_MFMA_TFLOPS}
-        roof.update({"avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch, "launches": cnn["launches"],
+        roof.update({"avg_launch_ms": cnn_avg_ms, "leaves_per_launch": leaves_per_launch, "launches": m["launches"],
+                     "timed_launches": cnn["launches"],
+                     "timing": ("HIP events around every launch of the window" if timed_share > 0.999 else
+                                "HIP events around every launch of blocks of 64 consecutive rounds out of every 512 (az_set_profiling "
+                                "mode 4); busy_ms / sum_launch_ms are the blocks' own"),
                      "busy_ms": cnn["busy_ms"], "sum_launch_ms": cnn["ms"], "concurrent_cohorts": eng.n_cohorts,
                      "achieved_per_launch": (3 if k3 == "split" else 1) * FLOP_PER_LEAF * leaves_per_launch
                                             / (max(cnn_avg_ms, 1e-9) * 1e-3) / 1e12})
@@ -599,7 +615,8 @@ def main(argv=None):
                        "x_reference_python_1thread": None if nb else games_s / REF_PY_GAMES_PER_S},
             "roofline": roofline(m, args.k3),
             "roofline_tree_step": None if nb else roofline_tree_step(m),
-            "kernel_time_ms": {k: v["ms"] for k, v in m["prof"].items()},
+            "kernel_time_ms": {k: v["ms"] for k, v in m["prof"].items()},      # summed over the TIMED launches only
+            "kernel_time_ms_timed_launches": {k: v["launches"] for k, v in m["prof"].items()},
             "box": _box_info(torch, local),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -149,7 +149,9 @@ int az_reset_stats(az_engine *e);
  * Categories: 0 = CNN leaf evaluation (K3), 1 = select (K2), 2 = expand/backup (K2), 3 = fused search (K2).
  * az_get_profile returns accumulated milliseconds and launch counts since az_set_profiling(e, on);
  * on = 1: every category, 2: the CNN launches only (half the events to record and read back), 3: the CNN launches and, of
- * the other categories, every fourth launch of the first cohort only (a sample: 1 in 16 with four cohorts), 0: off. */
+ * the other categories, every fourth launch of the first cohort only (a sample: 1 in 16 with four cohorts), 4: blocks of
+ * 64 consecutive rounds out of every 512 -- inside a block every cohort's CNN launch and the first cohort's tree step,
+ * outside it nothing (an event is a queue packet between two dependent kernels: ~6 us per gap), 0: off. */
 int az_set_profiling(az_engine *e, int on);
 int az_get_profile(az_engine *e, double *ms4, int64_t *launches4);
 /* per category, the time (ms) during which at least one launch of it was executing: the union of the launches'

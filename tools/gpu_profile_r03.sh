@@ -14,6 +14,9 @@ if [ $PART = bench ] || [ $PART = all ]; then
   grep '"metric"' $O/bench_stats.log > $O/bench_line.json
   run timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/bench_off -o bench -- $B --eval-cache -1 > $O/bench_off_stats.log 2>&1
   grep '"metric"' $O/bench_off_stats.log > $O/bench_off_line.json
+  # the same without the HIP events of bench.py's own kernel timing: what the event packets add to the gaps between kernels
+  run timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/bench_noev -o bench -- $B --no-profile > $O/bench_noev_stats.log 2>&1
+  grep '"metric"' $O/bench_noev_stats.log > $O/bench_noev_line.json
   # HBM traffic of the bench's own K3 / tree-step launches (PMC serialises the dispatches; counts are per launch all the same)
   P="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-second-leg --mean-plies 33.1 --preroll 4"
   run timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/bench_fetch -o pmc -- $P > $O/bench_fetch.log 2>&1

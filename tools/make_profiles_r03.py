@@ -53,6 +53,11 @@ def bench():
         f.write(cap(rs.kernel_stats, db))
         f.write(cap(rs.chain_stats, db, 0.2))
         f.write("## bench.py JSON line of that run:\n" + open(os.path.join(O, "bench_off_line.json")).read())
+        db = os.path.join(O, "bench_noev", "bench_results.db")
+        if os.path.exists(db):
+            f.write("\n# the headline run again with bench.py --no-profile (no HIP events around the kernels): the gaps between a stream's kernels\n")
+            f.write(cap(rs.chain_stats, db, 0.2))
+            f.write("## bench.py JSON line of that run:\n" + open(os.path.join(O, "bench_noev_line.json")).read())
     with open(os.path.join(T, "r03_k3_pmc.txt"), "w") as f:
         f.write("# rocprofv3 --pmc passes on bench.py --steps 1 --warmup 1 --preroll 4 (evaluation cache on: K3 launches of ~260 leaves, "
                 "tree steps of 512 games with up to 7 playouts per game); one pass per counter set, never combined with tracing.\n"
