@@ -568,6 +568,7 @@ __device__ inline bool backup_body(const Dev& d, int g, int gl, u32* p_idx, u32*
 struct Roll {
     int on;        // 0: lockstep tree step
     int cap;       // terminal playouts a game may finish in place per round
+    u32 budget;    // 0, or: no further in-place playout is started once the launch is this many 10 ns ticks old
     int S;         // playouts per move
     int first_n;   // game.py:41 temperature schedule (<0: temp for every ply)
     int move_mode, reuse;
@@ -608,7 +609,8 @@ __device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int
 // one playout to the next (as in the fused kernel) and goes back to memory at a ply end and at the end of the round: a
 // playout's dependent chain is then the walk itself plus one table probe.
 template <class G>
-__device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt) {
+__device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt,
+                                        u64 t_start) {
     constexpr int LG = G::LG;
     // an idle slot (parked, or its game is over and was not refilled) is left exactly as it is -- a parked leaf stays parked
     if (!d.active[g]) return;
@@ -622,6 +624,9 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
     float rQ = as_f(rr.y);
     bool parked = false;
     for (int it = 0; it <= r.cap; it++) {
+        // the launch lasts as long as its slowest game: past the time budget no game starts another in-place playout (which
+        // playouts run in which round changes nothing in any game: each game's playouts follow one another all the same)
+        if (it > 0 && r.budget && __builtin_amdgcn_s_memrealtime() - t_start > (u64)r.budget) break;
         typename G::State s = rs;   // env.copy()
         Leaf lf = walk<G>(d, nodes, s, root, rN, rQ, rlink, gl, p_idx, p_N, p_Q);
         typename G::State aug;
@@ -727,13 +732,14 @@ __device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clea
     const int grp = wave * GPW + lane / LG, gl = lane % LG;
     const int g = d.g0 + blockIdx.x * GPB + grp;
     if (g >= d.g0 + d.gn) return;
+    const u64 t_start = r.on && r.budget ? __builtin_amdgcn_s_memrealtime() : 0ull;
     bool played = false;
     Cnt cnt;
     if (mode & 1) played = backup_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
     if (r.on) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (played) roll_playout_done<G>(d, r, g, gl);
-        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
+        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt, t_start);
     } else if (mode & 2) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
@@ -1130,11 +1136,19 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     Roll r;
     memset(&r, 0, sizeof(r));
     r.on = 1;
-    static const char* cap_env = getenv("AZ_ROLL_CAP");   // tuning hook
-    // in-place playouts per game and round: 3 when only terminal playouts are finished in place (round 2's measurement);
-    // with the evaluation cache most playouts are, and 6 measured best (2 048 slots: cap 4 / 6 / 8 -> 2 411 / 2 494 / 2 447
-    // games/s; 16 384 slots: cap 3 / 6 / 10 -> 4 621 / 4 972 / 5 023)
-    r.cap = cap_env ? atoi(cap_env) : (d.cache ? 6 : 3);
+    static const char* cap_env = getenv("AZ_ROLL_CAP");         // tuning hooks
+    static const char* bud_env = getenv("AZ_ROLL_BUDGET_US");
+    // In-place playouts per game and round.  Without the evaluation cache only terminal playouts are finished in place: at most
+    // 3 (round 2's measurement).  With it most playouts are, a launch lasts as long as its slowest game, and a fixed count makes
+    // every launch as long as the deepest game's chain of that many playouts (cap 4 / 6 / 8 -> 2 411 / 2 494 / 2 447 games/s at
+    // 2 048 slots).  So the limit is the launch's AGE instead: no game starts another in-place playout once the launch is
+    // `budget` old (s_memrealtime, 10 ns ticks); games with shallow trees get through more playouts in that time, none holds
+    // the launch up.  One box, cap 6 without budget against cap 16 with: 512 games per launch 2 989 -> 3 216 / 3 524 / 3 450 /
+    // 3 419 games/s for 50 / 70 / 90 / 110 us; 1 024 per launch 4 828 -> 4 828 / 5 057 / 5 166 for 80 / 110 / 150 us; 4 096 per launch
+    // 7 158 -> 6 752 / 7 377 / 7 685 / 8 090 for 100 / 150 / 200 / 300 us (another box: 7 665 / 7 884 / 7 426 for 300 / 450 / 600 us).
+    const double bud_us = bud_env ? atof(bud_env) : (d.cache ? (d.gn <= 768 ? 70.0 : (d.gn <= 1536 ? 160.0 : 350.0)) : 0.0);
+    r.budget = bud_us > 0 ? (u32)(bud_us * 100.0) : 0u;
+    r.cap = cap_env ? atoi(cap_env) : (d.cache ? (r.budget ? 16 : 6) : 3);
     r.S = S;
     r.first_n = first_n;
     r.move_mode = move_mode;
