@@ -268,7 +268,7 @@ static int prof_begin(az_engine* e, int cat, hipStream_t st) {
     // every round's chain: timing every tree step as well cost the bench 3 %; a sample of 1 in 4 n_cohorts does not show.
     if (e->prof_sample0 && cat != PROF_CNN && (st != e->stream || (e->prof_tick++ & 3u))) e->prof_skip = true;
     // az_set_profiling(e, 4): the event packets sit between dependent kernels of a cohort's chain and cost a bench round 6 us per
-    // gap (profiles/r03_bench_kernel_stats.txt: 213 us per round with events around every K3 launch, 199 us with none).  Mode 4
+    // gap (profiles/r03_bench_count6_stats.txt: 213 us per round with events around every K3 launch, 199 us with none).  Mode 4
     // times blocks of 64 consecutive rounds out of every 512: inside a block every cohort's K3 launch (so that the union of
     // their intervals means something) and cohort 0's tree step; outside it nothing.  The cohorts' streams drift apart by a
     // round or two between two synchronisations, so short blocks of different cohorts do not coincide in time and the union

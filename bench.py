@@ -72,9 +72,9 @@ SPLIT_FLOP_PER_LEAF = 3 * FLOP_PER_LEAF   # az_cnn_split.hip: every fp32 product
 # HBM bytes per launch of the split kernel in THIS workload (PMC passes on bench.py itself, profiles/r03_k3_pmc.txt:
 # FETCH_SIZE 8079.5 KB x 2 + WRITE_SIZE 17.7 KB; round 2, without the evaluation cache: 8271.7 KB x 2 + 18.1 KB): the 2.0 MB of
 # split weights once per XCD L2 per launch, whatever the launch's size; positions in and outputs out are ~12 KB of it
-K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8079.5 + 17.7) * 1024
+K3_SPLIT_TRAFFIC_BYTES_PER_LAUNCH = (2 * 8144.8 + 17.4) * 1024
 K3_SPLIT_TRAFFIC_SOURCE = "rocprofv3 PMC passes on bench.py, profiles/r03_k3_pmc.txt"
-TREE_STEP_TRAFFIC_BYTES_PER_LAUNCH = (2 * 1078.0 + 470.4) * 1024   # same passes: k_tree_step<C4, 512, 2>, 512 games per launch
+TREE_STEP_TRAFFIC_BYTES_PER_LAUNCH = (2 * 1084.3 + 463.8) * 1024   # same passes: k_tree_step<C4, 512, 2>, 512 games per launch
 DEFAULT_K3 = "split"             # the headline kernel = the library's product kernel
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per k_search_fused<NBTTT> launch at 16 384 games x 800 playouts from the PMC passes of tools/gpu_profile_r03.sh
@@ -438,7 +438,7 @@ def main(argv=None):
         # the fused-search workload has one launch per step: time them all
         # CNN workloads, rolling: mode 4 = blocks of 64 consecutive rounds out of every 512, inside a block every cohort's K3 launch
         # and the first cohort's tree step (an event record is a packet between two dependent kernels of a cohort's chain:
-        # events around every K3 launch stretch a 199 us round to 213 us, profiles/r03_bench_kernel_stats.txt).  AZ_BENCH_PROF=3
+        # events around every K3 launch stretch a 199 us round to 213 us, profiles/r03_bench_count6_stats.txt).  AZ_BENCH_PROF=3
         # times every K3 launch + every fourth tree step of the first cohort, =1 everything.
         pmode = 0 if args.no_profile else (1 if args.profile_all or nb else int(os.environ.get("AZ_BENCH_PROF", "4" if args.mode == "rolling" else "3")))
         eng.set_profiling(pmode)
@@ -487,7 +487,7 @@ def main(argv=None):
                         "HBM (DESIGN.md 4.1); algorithmic bytes priced against the HBM peak as SURVEY 8d asks"}
 
     def roofline_tree_step(m):
-        """The other kernel of a CNN-workload round, k_tree_step (backup of the evaluated playout, ply ends, up to 1 + cap walks
+        """The other kernel of a CNN-workload round, k_tree_step (backup of the evaluated playout, ply ends, as many walks as fit the launch's time budget
         with cache probes): HBM class by SURVEY 8d's definition, latency-bound in fact.  Algorithmic bytes from
         the run's counters: select levels x (16 k + 8), backup (levels + playouts) x 8, expand children x 16 + 4 per
         expansion, one 64-byte cache probe per non-terminal playout and one 64-byte insert per network evaluation; duration
@@ -510,7 +510,7 @@ def main(argv=None):
                 "avg_launch_ms": avg_ms, "sampled_launches": b["launches"], "launches": launches_all,
                 "algorithmic_bytes_per_launch": per_launch, "playouts_per_launch": m["playouts"] / world / max(launches_all, 1),
                 "bytes_per_playout": by * world / max(m["playouts"], 1),
-                "note": "a launch lasts as long as one game's chain of up to 1 + cap dependent playouts (~14 us each beside K3): "
+                "note": "a launch lasts as long as one game's chain of dependent playouts (~14 us each beside K3) within its time budget: "
                         "latency-bound, the HBM roof is not what limits it"}
 
     def roofline(m, k3):
