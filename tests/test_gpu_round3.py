@@ -6,7 +6,8 @@
   * az_set_active in the middle of rolling self-play: a parked slot's game, tree and trajectory do not move, and the games
     come out the same as without parking;
   * az_net_load on a live engine with a blob that is refused: the engine keeps the weights it had;
-  * AZ_TREE_GPW values that are not a power of two: every game is still searched.
+  * AZ_TREE_GPW values that are not a power of two (ADVICE round 2): every game is still searched;
+  * the evaluation cache and the rolling tree step's time budget change which work runs when, never what a game does.
 """
 import os
 
@@ -236,6 +237,46 @@ def test_fused_search_covers_every_game_for_any_gpw():
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AZ_TREE_GPW=str(gpw)),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert p.returncode == 0, (gpw, p.stderr.decode()[-1500:])
+
+
+# ------------------------------------------------------------------------------------------------ in-place playout budget
+def test_rolling_time_budget_changes_nothing_in_any_game():
+    """The rolling tree step stops starting in-place playouts once its launch is AZ_ROLL_BUDGET_US old (read once per process,
+    so each value runs in a process of its own): which playout runs in which round depends on the clock, what a game does must
+    not.  Budget off with the old count of 6, the default, a budget so short that every round runs one playout per game, and
+    one so long that only the safety count (here 3 and 40) ends a round: the same games bit for bit, the same counters."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from alphazero_amd.engine import SelfPlayEngine\n"
+        "blob = np.fromfile(%r, dtype='<f4')\n"
+        "e = SelfPlayEngine('Connect4', n_games=160, n_playout=48, c_puct=1.25, evaluator='cnn', flip='random', reuse_tree=True,\n"
+        "                   dirichlet_alpha=0.7, rng_seed=5, move='sample', n_cohorts=2)\n"
+        "e.load_net(blob)\n"
+        "assert e.selfplay_rolling(320, temp=1.0, first_n_steps=6) == 320\n"
+        "t, s = e.traj_fetch(), e.stats()\n"
+        "o = np.lexsort((np.arange(len(t['game_id'])), t['game_id']))\n"
+        "h = hashlib.sha256()\n"
+        "for k in ('game_id', 'states', 'action', 'player', 'done', 'z', 'pi'):\n"
+        "    h.update(np.ascontiguousarray(t[k][o]).tobytes())\n"
+        "print(json.dumps(dict(sha=h.hexdigest(), rows=int(len(o)), **{k: int(s[k]) for k in ('playouts', 'terminal_hits', 'levels',\n"
+        "      'children', 'plies', 'games_finished')}, nonterminal=int(s['leaf_evals'] + s['cache_hits']))))\n"
+        % (ROOT, os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32")))
+    res = {}
+    for name, env in (("count6", dict(AZ_ROLL_BUDGET_US="0", AZ_ROLL_CAP="6")), ("default", {}),
+                      ("tiny", dict(AZ_ROLL_BUDGET_US="0.05")), ("count3", dict(AZ_ROLL_BUDGET_US="100000", AZ_ROLL_CAP="3")),
+                      ("count40", dict(AZ_ROLL_BUDGET_US="100000", AZ_ROLL_CAP="40"))):
+        e = {k: v for k, v in os.environ.items() if k not in ("AZ_ROLL_BUDGET_US", "AZ_ROLL_CAP")}
+        p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, (name, p.stderr.decode()[-1500:])
+        res[name] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    for name in res:
+        assert res[name] == res["count6"], (name, res[name], res["count6"])
+    assert res["default"]["rows"] > 320 * 7
 
 
 # ------------------------------------------------------------------------------------------------ evaluation cache
