@@ -1146,7 +1146,9 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     // the launch up.  One box, cap 6 without budget against cap 16 with: 512 games per launch 2 989 -> 3 216 / 3 524 / 3 450 /
     // 3 419 games/s for 50 / 70 / 90 / 110 us; 1 024 per launch 4 828 -> 4 828 / 5 057 / 5 166 for 80 / 110 / 150 us; 4 096 per launch
     // 7 158 -> 6 752 / 7 377 / 7 685 / 8 090 for 100 / 150 / 200 / 300 us (another box: 7 665 / 7 884 / 7 426 for 300 / 450 / 600 us).
-    const double bud_us = bud_env ? atof(bud_env) : (d.cache ? (d.gn <= 768 ? 70.0 : (d.gn <= 1536 ? 160.0 : 350.0)) : 0.0);
+    // ... and 2 048 per launch 5 232 -> 5 770 / 5 428 for 200 / 350 us, 1 024 per launch 5 270 / 5 127 / 4 894 for 120 / 160 / 200 us:
+    // the best budget grows with the launch (more games per wave, more waves per SIMD): 40 us + 1 us per 16 games.
+    const double bud_us = bud_env ? atof(bud_env) : (d.cache ? std::min(40.0 + d.gn / 16.0, 400.0) : 0.0);
     r.budget = bud_us > 0 ? (u32)(bud_us * 100.0) : 0u;
     r.cap = cap_env ? atoi(cap_env) : (d.cache ? (r.budget ? 16 : 6) : 3);
     r.S = S;
