@@ -616,17 +616,35 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         if (cenv && atoi(cenv) == 0) want = -1;
         else if (cenv && atoi(cenv) > 0 && want == 0) want = 1ll << std::min(atoi(cenv), 31);
         if (cfg->evaluator == AZ_EVAL_CNN && want >= 0) {
-            if (want == 0) want = std::min<i64>(std::max<i64>(G * 131072, 1ll << 16), 1ll << 30);
+            const bool auto_size = want == 0;
+            if (auto_size) want = std::min<i64>(std::max<i64>(G * 131072, 1ll << 16), 1ll << 30);
             i64 n = 1;
             while (n < want && n < (1ll << 31)) n <<= 1;
             uint4* tab = nullptr;
-            int rcc = e->dalloc(&tab, (size_t)n * 4);
+            int rcc = AZ_OK;
+            if (auto_size) {
+                // the table is an optimisation, never a reason to refuse an engine: an auto-sized one takes at most half of the
+                // memory that is free right now (other engines, the caller's own tensors) and halves again if hipMalloc says no;
+                // a size the caller asked for is allocated as asked or fails loudly
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess)
+                    while (n > (1ll << 16) && (size_t)n * 64 > fr / 2) n >>= 1;
+                while ((rcc = e->dalloc(&tab, (size_t)n * 4)) != AZ_OK && n > (1ll << 16)) {
+                    (void)hipGetLastError();
+                    n >>= 1;
+                }
+            } else {
+                rcc = e->dalloc(&tab, (size_t)n * 4);
+            }
+            // zeroed: hipMalloc may hand back a table of an engine that was destroyed earlier in this process
+            if (rcc == AZ_OK && hipMemset(tab, 0, (size_t)n * 64) != hipSuccess) {
+                set_error("hipMemset of the evaluation cache failed");
+                rcc = AZ_ERR_HIP;
+            }
             if (rcc != AZ_OK) {
                 az_engine_destroy(e);
                 return rcc;
             }
-            // zeroed: hipMalloc may hand back a table of an engine that was destroyed earlier in this process
-            (void)hipMemset(tab, 0, (size_t)n * 64);
             d.cache = tab;
             d.cache_mask = (u64)n - 1;
             e->cfg.eval_cache_entries = n;

@@ -93,8 +93,9 @@ typedef struct az_config {
                             /* network has already evaluated with the stored probs and value -- the very bits K3 delivers   */
                             /* (CNN.predict is a pure function of the position, Network.py:78-85), so every game's           */
                             /* trajectory is the same with the cache on or off; the reference evaluates every leaf anew      */
-                            /* (MCTS.py:146).  0 = auto (128 Ki entries = 8 MB per slot, 2^16 .. 2^30), < 0 = off.  az_net_load */
-                            /* empties it.  az_get_config reports the size in use (-1: none).                                 */
+                            /* (MCTS.py:146).  0 = auto (128 Ki entries = 8 MB per slot, 2^16 .. 2^30, and at most half of the */
+                            /* device memory free at creation), < 0 = off; a size given here is allocated as given or the     */
+                            /* engine is refused.  az_net_load empties it.  az_get_config reports the size in use (-1: none). */
 } az_config;
 
 typedef struct az_stats {

@@ -311,6 +311,30 @@ def test_evaluation_cache_changes_nothing_but_the_work(E, blob, rolling, noise):
           % (s0["leaf_evals"], out["auto"][1]["cache_hits"], out["tiny"][1]["cache_hits"]))
 
 
+def test_auto_sized_cache_yields_to_the_memory_that_is_left(E, blob):
+    """An auto-sized table (eval_cache_entries = 0) takes at most half of the device memory that is free when the engine is created;
+    a size the caller names is allocated as named or the engine is refused, loudly."""
+    import torch
+    from alphazero_amd._abi import AzError
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (12 << 30), 0), dtype=torch.uint8, device="cuda")    # leave ~12 GB
+    try:
+        left, _ = torch.cuda.mem_get_info()
+        eng = E.SelfPlayEngine("Connect4", n_games=2048, n_playout=8, c_puct=1.25, evaluator="cnn", flip="random",
+                               reuse_tree=True, rng_seed=3, move="sample", nodes_per_game=4096)
+        n = eng.eval_cache_entries
+        assert (1 << 16) <= n < (1 << 28) and n * 64 <= left // 2 + (1 << 20), (n, left)     # 2 048 slots would ask for 2^28 = 17 GB
+        eng.load_net(blob)
+        assert eng.selfplay_rolling(64, temp=1.0, first_n_steps=4) == 64
+        assert eng.stats()["cache_hits"] > 0
+        eng.close()
+        with pytest.raises(AzError):
+            E.SelfPlayEngine("Connect4", n_games=64, n_playout=8, evaluator="cnn", eval_cache=1 << 29)    # 34 GB: not there
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
 def test_evaluation_cache_is_emptied_by_a_hot_reload(E, blob):
     """Pipeline.py:87: after az_net_load on a live engine no leaf may be answered with the previous weights' output.  An engine
     that has filled its cache under checkpoint A and is then given checkpoint B must search exactly like a cache-less engine
