@@ -107,6 +107,7 @@ struct TmpBufs {
         hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) {
             set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
             return AZ_ERR_HIP;
         }
         v.push_back(q);
@@ -198,6 +199,7 @@ struct az_engine {
     int recording = 0;
     // rolling self-play (az_selfplay_rounds): leaves are parked between calls; parity of the leaf counter in use
     bool roll_started = false;
+    u32* search_cnt = nullptr;     // [2] az_search on the rolling step: games taking part, games complete
     int roll_par = 0;
     // cohorts: the slots are cut into C ranges whose select -> CNN -> backup chains run on their own streams, so one
     // cohort's tree kernels and the ragged last round of its CNN launch overlap with the other cohort's CNN launch.
@@ -226,6 +228,7 @@ struct az_engine {
         hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
         if (e != hipSuccess) {
             set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            (void)hipGetLastError();   // the runtime keeps the failure as its "last error": the next launch check would report it
             return AZ_ERR_HIP;
         }
         allocs.push_back(q);
@@ -905,6 +908,87 @@ int az_set_flip_stream(az_engine* e, const uint8_t* bits, int64_t n_per_game) {
     return AZ_OK;
 }
 
+// az_search for AZ_EVAL_CNN engines on the rolling tree step (az_tree.hip, Roll::search): every game runs its n_sims playouts one
+// after the other exactly as in the lockstep chain below, but a playout that ends on a terminal node, or on a position whose
+// evaluation is in the cache, is finished in place and the game walks on -- a round of { K3 ; tree step } is spent only on
+// leaves the network really has to see.  The lockstep chain spends one round on EVERY playout (500 rounds per move; late in a
+// game 20-60 % of them carry no leaf at all).  The number of rounds a search needs is not known ahead, so the host reads the
+// two counters every few rounds; the call returns when every game that takes part has had its n_sims playouts.  Used for
+// engines of a handful of games (az_search); both forms grow the same trees bit for bit (tests/test_gpu_round3.py).
+static int search_cnn_rolling(az_engine* e, int n_sims) {
+    const Dev& d = e->d;
+    const int C = e->C;
+    Dev dc[AZ_MAX_COHORTS][2];
+    hipStream_t cs[AZ_MAX_COHORTS];
+    for (int c = 0; c < C; c++) {
+        const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
+        for (int par = 0; par < 2; par++) {
+            dc[c][par] = d;
+            dc[c][par].g0 = (i32)lo;
+            dc[c][par].gn = (i32)(hi - lo);
+            dc[c][par].eval_count = d.eval_count + 4 * c + par;
+            dc[c][par].eval_list = d.eval_list + lo;
+        }
+        cs[c] = c == 0 ? e->stream : e->cstream[c];
+    }
+    if (!e->search_cnt) AZ_TRY(e->dalloc(&e->search_cnt, 2));
+    AZ_HIP(hipMemsetAsync(e->search_cnt, 0, 2 * sizeof(u32), e->stream));
+    AZ_HIP(hipMemsetAsync(d.move_sims, 0, (size_t)d.G * sizeof(i32), e->stream));
+    auto fork = [&]() -> int {
+        if (C > 1) {
+            AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
+            for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
+        }
+        return AZ_OK;
+    };
+    auto join = [&]() -> int {
+        for (int c = 1; c < C; c++) {
+            AZ_HIP(hipEventRecord(e->ev_join[c], cs[c]));
+            AZ_HIP(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+        }
+        return AZ_OK;
+    };
+    auto roll = [&](const Dev& dd, int mode, u32* stale, hipStream_t st) {
+        return launch_roll_step(dd, mode, stale, e->p, n_sims, 1.0, -1, e->cfg.move_mode, e->cfg.reuse_tree, 0ull,
+                                e->cfg.game_id_base, st, e->search_cnt);
+    };
+    AZ_TRY(fork());
+    for (int c = 0; c < C; c++) {
+        AZ_TRY(prof_begin(e, PROF_SELECT, cs[c]));
+        AZ_TRY(roll(dc[c][0], 2, nullptr, cs[c]));
+        AZ_TRY(prof_end(e, cs[c]));
+    }
+    int par = 0, rounds = 0;
+    u32 cnt[2] = {1u, 0u};
+    // rounds between two looks at the counters: a look drains the streams (a few tens of microseconds)
+    int chunk = std::max(4, std::min(32, n_sims / 8));
+    while (cnt[1] < cnt[0]) {
+        if (rounds > n_sims + 64) {   // every playout a miss is n_sims rounds: more than that is a bug, not a long search
+            set_error("az_search: the rolling search did not complete");
+            return AZ_ERR_STATE;
+        }
+        for (int k = 0; k < chunk; k++, rounds++) {
+            for (int c = 0; c < C; c++) {
+                AZ_TRY(prof_begin(e, PROF_CNN, cs[c]));
+                AZ_TRY(cnn_eval_leaves(e->net, dc[c][par], cs[c]));
+                AZ_TRY(prof_end(e, cs[c]));
+                AZ_TRY(prof_begin(e, PROF_BACKUP, cs[c]));
+                AZ_TRY(roll(dc[c][par ^ 1], 3, dc[c][par].eval_count, cs[c]));
+                AZ_TRY(prof_end(e, cs[c]));
+            }
+            par ^= 1;
+        }
+        AZ_TRY(join());
+        AZ_HIP(hipMemcpyAsync(cnt, e->search_cnt, sizeof(cnt), hipMemcpyDeviceToHost, e->stream));
+        AZ_HIP(hipStreamSynchronize(e->stream));
+        if (cnt[1] < cnt[0]) AZ_TRY(fork());
+    }
+    // nothing is parked now (a complete game selects no further leaf) and both leaf counters are zero; the per-move counter goes
+    // back to zero for the rolling self-play entry points
+    AZ_HIP(hipMemsetAsync(d.move_sims, 0, (size_t)d.G * sizeof(i32), e->stream));
+    return AZ_OK;
+}
+
 int az_search(az_engine* e, int32_t n_sims) {
     AZ_CHECK_E(e);
     if (n_sims <= 0) n_sims = e->cfg.n_playout;
@@ -928,6 +1012,12 @@ int az_search(az_engine* e, int32_t n_sims) {
             set_error("AZ_EVAL_CNN: call az_net_load first");
             return AZ_ERR_NO_NET;
         }
+        // A handful of games (the drop-in player's single game, BASELINE configs[0]): the rolling form.  One game, 500 playouts per
+        // move, ms per move: first game of an engine 20.4 -> 19.0, a game whose positions the cache already holds 7.95 -> 4.5.  Many
+        // games: the lockstep chain -- a search then lasts as long as the game with the most misses whatever the form, and the
+        // chain's rounds are shorter (256 games: 38.0 ms per move against 40.6).  AZ_SEARCH_ROLL=0|1 forces one form (A/B, parity).
+        static const char* sr_env = getenv("AZ_SEARCH_ROLL");
+        if (sr_env ? atoi(sr_env) != 0 : d.G <= 8) return search_cnn_rolling(e, n_sims);
         // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
         // (disjoint slots, own leaf list and counter) and are issued round-robin onto their own streams.
         const int C = e->C;

@@ -89,6 +89,7 @@ void set_error(const std::string& s);
         hipError_t _e = (call);                                                              \
         if (_e != hipSuccess) {                                                              \
             az::set_error(std::string(#call) + ": " + hipGetErrorString(_e));                \
+            (void)hipGetLastError(); /* reported here: not again by a later launch check */  \
             return AZ_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)

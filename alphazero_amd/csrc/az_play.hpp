@@ -35,8 +35,10 @@ int launch_ply_end(const Dev& d, const Play& p, double temp_all, int first_n, in
 int launch_init_slots(const Dev& d, int use_openings, u64 gid_base, hipStream_t st);
 // rolling self-play tree step (az_tree.hip): mode 2 = the very first selection, 3 = finish round i (with the ply ends that
 // fall into it) and select round i+1; stale_count = the leaf counter the evaluator has just consumed (cleared here).
+// search_cnt != null: az_search on the rolling step (S = playouts of this search, no ply ends): [0] counts the games that take
+// part (mode 2), [1] the games whose S playouts are complete
 int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, int S, double temp, int first_n, int move_mode,
-                     int reuse, unsigned long long target, u64 gid_base, hipStream_t st);
+                     int reuse, unsigned long long target, u64 gid_base, hipStream_t st, u32* search_cnt = nullptr);
 int launch_traj_pack(int game, const Play& p, i64 n, u8* out, hipStream_t st);
 int launch_traj_unpack(int game, i64 n, const u8* recs, float* state, float* prob, float* value, i32* winner,
                        float* next_state, u8* done, hipStream_t st);

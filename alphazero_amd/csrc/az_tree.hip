@@ -569,6 +569,8 @@ struct Roll {
     int on;        // 0: lockstep tree step
     int cap;       // terminal playouts a game may finish in place per round
     u32 budget;    // 0, or: no further in-place playout is started once the launch is this many 10 ns ticks old
+    int search;    // az_search on the rolling step: a game stops after its S playouts (no ply end).  2: the first selection
+    u32* search_cnt;   // search: [0] games that take part, [1] games whose S playouts are complete
     int S;         // playouts per move
     int first_n;   // game.py:41 temperature schedule (<0: temp for every ply)
     int move_mode, reuse;
@@ -597,6 +599,14 @@ template <class G>
 __device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int gl) {
     const int ms = d.move_sims[g] + 1;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (r.search) {   // az_search: the S-th playout completes the game's search; nothing else happens
+        if (gl == 0) {
+            d.move_sims[g] = ms;
+            if (ms >= r.S) atomicAdd(&r.search_cnt[1], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        return;
+    }
     if (gl == 0) d.move_sims[g] = ms >= r.S ? 0 : ms;
     if (ms >= r.S) roll_ply_end<G>(d, r, g, gl);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -619,6 +629,10 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
     u32 root = d.root[g], nalloc = d.n_alloc[g], fpos = d.flip_pos[g];
     u64 ctr = d.sim_ctr[g];
     int ms = d.move_sims[g];
+    if (r.search) {
+        if (r.search == 2 && gl == 0) atomicAdd(&r.search_cnt[0], 1u);   // the first selection counts the games that take part
+        if (ms >= r.S) return;                                            // this game has had its S playouts
+    }
     uint4 rr = nodes[root];
     u32 rN = rr.x, rlink = rr.w;
     float rQ = as_f(rr.y);
@@ -669,6 +683,17 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
         if (hit) cnt.hits++, cnt.children += st_children;
         else cnt.term++;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (r.search && ms + 1 >= r.S) {   // az_search: the game's S-th playout; its state goes back to memory and it rests
+            if (gl == 0) {
+                d.n_alloc[g] = nalloc;
+                d.sim_ctr[g] = ctr;
+                d.flip_pos[g] = fpos;
+                d.move_sims[g] = ms + 1;
+                d.leaf_flags[g] = 0u;
+                atomicAdd(&r.search_cnt[1], 1u);
+            }
+            return;
+        }
         if (++ms >= r.S) {   // the move is complete: state back to memory, ply end, and the new root's state in again
             ms = 0;
             if (gl == 0) {
@@ -1132,10 +1157,12 @@ int launch_backup_select(const Dev& d, u32* stale_count, hipStream_t st) {
 }
 // rolling self-play: mode 2 = the very first selection, 3 = finish round i (+ ply ends) and select round i+1
 int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, int S, double temp, int first_n, int move_mode,
-                     int reuse, unsigned long long target, u64 gid_base, hipStream_t st) {
+                     int reuse, unsigned long long target, u64 gid_base, hipStream_t st, u32* search_cnt) {
     Roll r;
     memset(&r, 0, sizeof(r));
     r.on = 1;
+    r.search = search_cnt ? (mode == 2 ? 2 : 1) : 0;
+    r.search_cnt = search_cnt;
     static const char* cap_env = getenv("AZ_ROLL_CAP");         // tuning hooks
     static const char* bud_env = getenv("AZ_ROLL_BUDGET_US");
     // In-place playouts per game and round.  Without the evaluation cache only terminal playouts are finished in place: at most
@@ -1151,6 +1178,9 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     const double bud_us = bud_env ? atof(bud_env) : (d.cache ? std::min(40.0 + d.gn / 16.0, 400.0) : 0.0);
     r.budget = bud_us > 0 ? (u32)(bud_us * 100.0) : 0u;
     r.cap = cap_env ? atoi(cap_env) : (d.cache ? (r.budget ? 16 : 6) : 3);
+    // az_search over a handful of games (the drop-in player's single game): nobody waits for anybody, a game walks until it finds a
+    // leaf for the network
+    if (search_cnt && d.gn <= 8 && !bud_env && !cap_env) r.budget = 0u, r.cap = 64;
     r.S = S;
     r.first_n = first_n;
     r.move_mode = move_mode;

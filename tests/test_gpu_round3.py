@@ -279,6 +279,48 @@ def test_rolling_time_budget_changes_nothing_in_any_game():
     assert res["default"]["rows"] > 320 * 7
 
 
+# ------------------------------------------------------------------------------------------------ az_search, rolling form
+def test_az_search_rolling_form_grows_the_same_trees():
+    """az_search on an AZ_EVAL_CNN engine of a handful of games runs on the rolling tree step (terminal playouts and cache hits
+    finished in place, a round only for leaves the network has to see); larger engines keep the lockstep chain.
+    AZ_SEARCH_ROLL=0|1 forces one form for every size (read once per process): both must grow the same trees -- actions,
+    visit counts, Q and prior bit patterns of every root, and the moves played -- for 1, 5 and 200 games, eval and train mode."""
+    import hashlib
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from alphazero_amd.engine import SelfPlayEngine\n"
+        "blob = np.fromfile(%r, dtype='<f4')\n"
+        "h = hashlib.sha256()\n"
+        "for G, S, noise, plies in ((1, 300, 0.0, 12), (5, 120, 0.7, 10), (200, 64, 0.7, 6)):\n"
+        "    e = SelfPlayEngine('Connect4', n_games=G, n_playout=S, c_puct=1.25, evaluator='cnn', flip='random', reuse_tree=True,\n"
+        "                       dirichlet_alpha=noise, rng_seed=11, move='sample')\n"
+        "    e.load_net(blob)\n"
+        "    for ply in range(plies):\n"
+        "        e.search()\n"
+        "        rc = e.root_children()\n"
+        "        assert (rc['root_visits'] == (S if ply == 0 else rc['root_visits'])).all()\n"
+        "        a, _ = e.choose_moves(temp=1.0)\n"
+        "        for k in ('actions', 'visits', 'q', 'prior', 'n', 'root_visits'):\n"
+        "            h.update(np.ascontiguousarray(rc[k]).tobytes())\n"
+        "        h.update(a.tobytes())\n"
+        "        e.advance(a)\n"
+        "    st = e.stats()\n"
+        "    h.update(np.array([st[k] for k in ('playouts', 'terminal_hits', 'levels', 'children')], dtype=np.int64).tobytes())\n"
+        "    assert st['playouts'] == G * S * plies or G > 1, st\n"
+        "    e.close()\n"
+        "print(h.hexdigest())\n" % (ROOT, os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32")))
+    res = {}
+    for name, env in (("chain", dict(AZ_SEARCH_ROLL="0")), ("rolling", dict(AZ_SEARCH_ROLL="1")), ("default", {})):
+        e = {k: v for k, v in os.environ.items() if k != "AZ_SEARCH_ROLL"}
+        p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+        assert p.returncode == 0, (name, p.stderr.decode()[-1500:])
+        res[name] = p.stdout.decode().strip().splitlines()[-1]
+    assert res["chain"] == res["rolling"] == res["default"], res
+
+
 # ------------------------------------------------------------------------------------------------ evaluation cache
 @pytest.mark.parametrize("rolling", [True, False])
 @pytest.mark.parametrize("noise", [0.0, 0.7])
