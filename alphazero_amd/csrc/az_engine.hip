@@ -1016,6 +1016,10 @@ int az_search(az_engine* e, int32_t n_sims) {
         // move, ms per move: first game of an engine 20.4 -> 19.0, a game whose positions the cache already holds 7.95 -> 4.5.  Many
         // games: the lockstep chain -- a search then lasts as long as the game with the most misses whatever the form, and the
         // chain's rounds are shorter (256 games: 38.0 ms per move against 40.6).  AZ_SEARCH_ROLL=0|1 forces one form (A/B, parity).
+        if (e->roll_started) {   // az_selfplay_rounds keeps leaves parked and playout counters running between calls
+            set_error("az_search: rolling self-play is in progress on this engine (az_reset_games or az_set_roots first)");
+            return AZ_ERR_STATE;
+        }
         static const char* sr_env = getenv("AZ_SEARCH_ROLL");
         if (sr_env ? atoi(sr_env) != 0 : d.G <= 8) return search_cnn_rolling(e, n_sims);
         // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
