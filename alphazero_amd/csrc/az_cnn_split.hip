@@ -1156,7 +1156,11 @@ int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32
                 float* logv, float* probs, float* value, hipStream_t st) {
     if (max_n == 0) return AZ_OK;
     static const char* cfg = getenv("AZ_K3_SPLIT_CFG");   // tuning hook: "44" (4 positions, 4 waves), "48", "24"
-    const int kc = cfg ? atoi(cfg) : SPLIT_DEFAULT_CFG;
+    // A launch of a few leaves (the drop-in player's single game: one leaf) is ONE workgroup's latency whatever the form, and the
+    // two-position form's workgroup is the shortest (one workgroup alone: 52 us against 65 us for <3,4> and 95 us for <4,4>).  All
+    // forms deliver the same bits (tests/test_gpu_cnn.py::test_split_forms_deliver_the_same_bits), so what a launch's size
+    // selects never shows in a result.
+    const int kc = cfg ? atoi(cfg) : (max_n <= 64 ? 24 : SPLIT_DEFAULT_CFG);
     static const char* dsy = getenv("AZ_K3_SPLIT_DESYNC");
     const int desync = dsy ? atoi(dsy) : 0;
     if (kc == 316)   // the product configuration on v_mfma_f32_16x16x32_f16 (A/B form)

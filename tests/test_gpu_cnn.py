@@ -139,6 +139,32 @@ def test_cnn_ragged_batches_vs_oracle(eng, blob, n):
     np.testing.assert_allclose(probs.sum(1), 1.0, rtol=1e-5)
 
 
+def test_split_forms_deliver_the_same_bits(blob):
+    """The split-fp16 K3 evaluates launches of up to 64 leaves with two positions per workgroup and larger ones with three
+    (az_cnn_split.hip, cnns_launch): the same position must come out with the same bits from either form, or a launch's
+    size -- and with the evaluation cache, the history of a table -- would show in a result."""
+    from alphazero_amd.engine import SelfPlayEngine
+    rng = np.random.default_rng(77)
+    envs = []
+    while len(envs) < 300:
+        e = orc.Env("Connect4")
+        for _ in range(int(rng.integers(0, 34))):
+            if e.done():
+                break
+            e.step(int(rng.choice(e.valid_move())))
+        if not e.done():
+            envs.append(e)
+    packed = np.array([e.packed() for e in envs])
+    eng = SelfPlayEngine("Connect4", n_games=1, n_playout=1, evaluator="cnn")
+    eng.load_net(blob, kernel="split")
+    big = eng.net_forward(packed)                      # 300 leaves: three positions per workgroup
+    for lo, n in ((0, 1), (1, 2), (3, 7), (10, 64), (200, 33)):
+        small = eng.net_forward(packed[lo:lo + n])     # <= 64 leaves: two positions per workgroup
+        for a, b in zip(small, big):
+            assert np.array_equal(a.view(np.uint32), b[lo:lo + n].view(np.uint32)), (lo, n)
+    eng.close()
+
+
 def test_search_with_real_net_move_agreement(eng):
     """BASELINE config 1 head: S=500, eval mode, fresh tree per ply, recorded flips, real checkpoint.
     The fp32 MFMA forward and torch's CPU forward differ in the last bits, so visit counts are not expected to be
