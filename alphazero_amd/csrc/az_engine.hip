@@ -1015,13 +1015,14 @@ int az_search(az_engine* e, int32_t n_sims) {
         // A handful of games (the drop-in player's single game, BASELINE configs[0]): the rolling form.  One game, 500 playouts per
         // move, ms per move: first game of an engine 20.4 -> 19.0, a game whose positions the cache already holds 7.95 -> 4.5.  Many
         // games: the lockstep chain -- a search then lasts as long as the game with the most misses whatever the form, and the
-        // chain's rounds are shorter (256 games: 38.0 ms per move against 40.6).  AZ_SEARCH_ROLL=0|1 forces one form (A/B, parity).
+        // chain's rounds are shorter (ms per move, chain / rolling: 8 games 26.8 / 25.0, 16: 27.2 / 25.8, 32: 29.6 / 29.2, 64: 30.9 / 31.2,
+        // 256: 38.0 / 40.6).  AZ_SEARCH_ROLL=0|1 forces one form (A/B, parity).
         if (e->roll_started) {   // az_selfplay_rounds keeps leaves parked and playout counters running between calls
             set_error("az_search: rolling self-play is in progress on this engine (az_reset_games or az_set_roots first)");
             return AZ_ERR_STATE;
         }
         static const char* sr_env = getenv("AZ_SEARCH_ROLL");
-        if (sr_env ? atoi(sr_env) != 0 : d.G <= 8) return search_cnn_rolling(e, n_sims);
+        if (sr_env ? atoi(sr_env) != 0 : d.G <= 32) return search_cnn_rolling(e, n_sims);
         // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
         // (disjoint slots, own leaf list and counter) and are issued round-robin onto their own streams.
         const int C = e->C;
