@@ -908,6 +908,25 @@ int az_set_flip_stream(az_engine* e, const uint8_t* bits, int64_t n_per_game) {
     return AZ_OK;
 }
 
+// The engine's slots cut into its C cohorts: per cohort a view of the device state for each of the two leaf counters that
+// successive rounds alternate between, and the stream its chain runs on (cohort 0 rides on the engine stream: a process has
+// few hardware queues).
+static void cohort_views(const az_engine* e, Dev (*dc)[2], hipStream_t* cs) {
+    const Dev& d = e->d;
+    const int C = e->C;
+    for (int c = 0; c < C; c++) {
+        const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
+        for (int par = 0; par < 2; par++) {
+            dc[c][par] = d;
+            dc[c][par].g0 = (i32)lo;
+            dc[c][par].gn = (i32)(hi - lo);
+            dc[c][par].eval_count = d.eval_count + 4 * c + par;
+            dc[c][par].eval_list = d.eval_list + lo;
+        }
+        cs[c] = c == 0 ? e->stream : e->cstream[c];
+    }
+}
+
 // az_search for AZ_EVAL_CNN engines on the rolling tree step (az_tree.hip, Roll::search): every game runs its n_sims playouts one
 // after the other exactly as in the lockstep chain below, but a playout that ends on a terminal node, or on a position whose
 // evaluation is in the cache, is finished in place and the game walks on -- a round of { K3 ; tree step } is spent only on
@@ -920,17 +939,7 @@ static int search_cnn_rolling(az_engine* e, int n_sims) {
     const int C = e->C;
     Dev dc[AZ_MAX_COHORTS][2];
     hipStream_t cs[AZ_MAX_COHORTS];
-    for (int c = 0; c < C; c++) {
-        const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
-        for (int par = 0; par < 2; par++) {
-            dc[c][par] = d;
-            dc[c][par].g0 = (i32)lo;
-            dc[c][par].gn = (i32)(hi - lo);
-            dc[c][par].eval_count = d.eval_count + 4 * c + par;
-            dc[c][par].eval_list = d.eval_list + lo;
-        }
-        cs[c] = c == 0 ? e->stream : e->cstream[c];
-    }
+    cohort_views(e, dc, cs);
     if (!e->search_cnt) AZ_TRY(e->dalloc(&e->search_cnt, 2));
     AZ_HIP(hipMemsetAsync(e->search_cnt, 0, 2 * sizeof(u32), e->stream));
     AZ_HIP(hipMemsetAsync(d.move_sims, 0, (size_t)d.G * sizeof(i32), e->stream));
@@ -1028,17 +1037,7 @@ int az_search(az_engine* e, int32_t n_sims) {
         const int C = e->C;
         Dev dc[AZ_MAX_COHORTS][2];   // [cohort][leaf-counter parity]
         hipStream_t cs[AZ_MAX_COHORTS];
-        for (int c = 0; c < C; c++) {
-            const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
-            for (int par = 0; par < 2; par++) {
-                dc[c][par] = d;
-                dc[c][par].g0 = (i32)lo;
-                dc[c][par].gn = (i32)(hi - lo);
-                dc[c][par].eval_count = d.eval_count + 4 * c + par;
-                dc[c][par].eval_list = d.eval_list + lo;
-            }
-            cs[c] = c == 0 ? e->stream : e->cstream[c];   // cohort 0 rides on the engine stream (4 hardware queues)
-        }
+        cohort_views(e, dc, cs);
         if (C > 1) {  // fork: the cohort streams start after everything queued on the engine stream
             AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
             for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
@@ -1221,17 +1220,7 @@ int az_selfplay_rounds(az_engine* e, int32_t n_rounds, double temp, int32_t firs
     const int C = e->C, S = e->cfg.n_playout;
     Dev dc[AZ_MAX_COHORTS][2];
     hipStream_t cs[AZ_MAX_COHORTS];
-    for (int c = 0; c < C; c++) {
-        const i64 lo = (i64)d.G * c / C, hi = (i64)d.G * (c + 1) / C;
-        for (int par = 0; par < 2; par++) {
-            dc[c][par] = d;
-            dc[c][par].g0 = (i32)lo;
-            dc[c][par].gn = (i32)(hi - lo);
-            dc[c][par].eval_count = d.eval_count + 4 * c + par;
-            dc[c][par].eval_list = d.eval_list + lo;
-        }
-        cs[c] = c == 0 ? e->stream : e->cstream[c];
-    }
+    cohort_views(e, dc, cs);
     if (C > 1) {
         AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
         for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
