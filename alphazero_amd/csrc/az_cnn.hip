@@ -589,13 +589,12 @@ int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, 
 }
 
 int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
+    const unsigned max_n = (unsigned)d.gn * (unsigned)(1 + d.spec_rows);   // the cohort's slots (and their speculative rows) bound its leaf count
     if (c->split)
-        return cnns_launch(c->split, (unsigned)d.gn, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
-                           d.eval_probs, d.eval_value, st);
-    if (c->wino)   // the cohort's slots bound its leaf count
-        return cnnw_launch(c->wino, (unsigned)d.gn, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
-                           d.eval_probs, d.eval_value, st);
-    const unsigned grid = (unsigned)((d.gn + SPB - 1) / SPB);   // the cohort's slots bound its leaf count
+        return cnns_launch(c->split, max_n, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr, d.eval_probs, d.eval_value, st);
+    if (c->wino)
+        return cnnw_launch(c->wino, max_n, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr, d.eval_probs, d.eval_value, st);
+    const unsigned grid = (max_n + SPB - 1) / SPB;
     k_cnn_forward<<<dim3(grid), dim3(256), 0, st>>>(c->d, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr,
                                                     d.eval_probs, d.eval_value);
     AZ_HIP(hipGetLastError());

@@ -542,10 +542,30 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
     A_(d.leaf_depth, G);
     A_(d.leaf_flags, G);
     A_(d.leaf_tvalue, G);
-    A_(d.leaf_state, G * gi.W);
-    A_(d.eval_probs, G * gi.A);
-    A_(d.eval_value, G);
-    A_(d.eval_list, G);
+    // speculative rows (az_tree.hip "Speculation"): engines of up to a few hundred games whose leaves go through K3 and its
+    // evaluation cache -- first of all the drop-in player's single game.  2 kinds x LG lanes x 2 orientations per slot.
+    {
+        static const char* spec_env = getenv("AZ_SPEC");   // "0": off (A/B)
+        const bool cache_wanted = cfg->eval_cache_entries >= 0 && !(getenv("AZ_EVAL_CACHE") && atoi(getenv("AZ_EVAL_CACHE")) == 0);
+        // ms per move of az_search x 500 playouts, lockstep chain against rolling form with speculation (tools/single_game_rate.py): 1
+        // game 16.7 -> 6.9, 8 games 25.1 -> 13.8, 16: 26.1 -> 15.1, 32: 29.2 -> 16.5, 64: 30.9 -> 17.7, 128: 36.8 -> 20.9, 256: 37.8 -> 25.2,
+        // 512: 38.0 -> 31.5, 1 024: 40.4 -> 46.0 (a K3 launch carries up to 33 rows per game: from a thousand games on the extra rows
+        // cost more CU time than the rounds they save), 2 048: 84.7 -> 83.5
+        static const char* specg_env = getenv("AZ_SPEC_MAX_G");   // measurement hook
+        const int spec_max_g = specg_env ? atoi(specg_env) : 512;
+        d.spec_rows = (cfg->evaluator == AZ_EVAL_CNN && cfg->game == AZ_GAME_C4 && G <= spec_max_g && cache_wanted &&
+                       !(spec_env && atoi(spec_env) == 0)) ? 32 : 0;
+        d.spec_mark = nullptr;
+    }
+    const i64 rows = (i64)G * (1 + d.spec_rows);
+    A_(d.leaf_state, rows * gi.W);
+    A_(d.eval_probs, rows * gi.A);
+    A_(d.eval_value, rows);
+    A_(d.eval_list, rows);
+    if (d.spec_rows) {
+        A_(d.spec_mark, (i64)G * d.spec_rows);
+        if (rc == AZ_OK) (void)hipMemset(d.spec_mark, 0, (size_t)G * d.spec_rows);
+    }
     A_(d.eval_count, 4 * AZ_MAX_COHORTS);
     A_(d.winner, G);
     A_(d.done, G);
@@ -620,7 +640,8 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         else if (cenv && atoi(cenv) > 0 && want == 0) want = 1ll << std::min(atoi(cenv), 31);
         if (cfg->evaluator == AZ_EVAL_CNN && want >= 0) {
             const bool auto_size = want == 0;
-            if (auto_size) want = std::min<i64>(std::max<i64>(G * 131072, 1ll << 16), 1ll << 30);
+            // (with speculative rows thirteen positions enter the table for every one a game asks for: 2^22 entries at least)
+            if (auto_size) want = std::min<i64>(std::max<i64>(G * 131072, d.spec_rows ? 1ll << 22 : 1ll << 16), 1ll << 30);
             i64 n = 1;
             while (n < want && n < (1ll << 31)) n <<= 1;
             uint4* tab = nullptr;
@@ -921,7 +942,7 @@ static void cohort_views(const az_engine* e, Dev (*dc)[2], hipStream_t* cs) {
             dc[c][par].g0 = (i32)lo;
             dc[c][par].gn = (i32)(hi - lo);
             dc[c][par].eval_count = d.eval_count + 4 * c + par;
-            dc[c][par].eval_list = d.eval_list + lo;
+            dc[c][par].eval_list = d.eval_list + lo * (1 + d.spec_rows);   // a cohort's list holds its slots' rows and their speculative rows
         }
         cs[c] = c == 0 ? e->stream : e->cstream[c];
     }
@@ -1021,7 +1042,7 @@ int az_search(az_engine* e, int32_t n_sims) {
             set_error("AZ_EVAL_CNN: call az_net_load first");
             return AZ_ERR_NO_NET;
         }
-        // A handful of games (the drop-in player's single game, BASELINE configs[0]): the rolling form.  One game, 500 playouts per
+        // A handful of games (the drop-in player's single game, BASELINE configs[0]), and every engine with speculative rows: the rolling form.  One game, 500 playouts per
         // move, ms per move: first game of an engine 20.4 -> 19.0, a game whose positions the cache already holds 7.95 -> 4.5.  Many
         // games: the lockstep chain -- a search then lasts as long as the game with the most misses whatever the form, and the
         // chain's rounds are shorter (ms per move, chain / rolling: 8 games 26.8 / 25.0, 16: 27.2 / 25.8, 32: 29.6 / 29.2, 64: 30.9 / 31.2,
@@ -1031,7 +1052,7 @@ int az_search(az_engine* e, int32_t n_sims) {
             return AZ_ERR_STATE;
         }
         static const char* sr_env = getenv("AZ_SEARCH_ROLL");
-        if (sr_env ? atoi(sr_env) != 0 : d.G <= 32) return search_cnn_rolling(e, n_sims);
+        if (sr_env ? atoi(sr_env) != 0 : (d.G <= 32 || d.spec_rows > 0)) return search_cnn_rolling(e, n_sims);
         // One chain select -> CNN -> backup per cohort and playout.  The chains of different cohorts are independent
         // (disjoint slots, own leaf list and counter) and are issued round-robin onto their own streams.
         const int C = e->C;

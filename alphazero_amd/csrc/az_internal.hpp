@@ -68,6 +68,10 @@ struct Dev {
     float* eval_value;    // [G]
     u32* eval_list;       // [G] compacted list of slots whose leaf needs the network (a cohort's list starts at g0)
     u32* eval_count;      // [1] per cohort; k_select counts up, k_backup clears it for the next round
+    // speculative evaluation (az_search of a handful of games, az_tree.hip "Speculation"): spec_rows extra rows per slot behind the
+    // G slot rows of leaf_state / eval_probs / eval_value / eval_list (row G + g * spec_rows + r), 0 = off
+    i32 spec_rows;
+    u8* spec_mark;        // [G][spec_rows] 1 = the row holds a position whose evaluation goes into the cache at the next tree step
     // status
     i8* winner;           // [G]
     u8* done;             // [G]

@@ -180,9 +180,17 @@ struct Leaf {
 };
 
 // MCTS.py:108-113 (select_leaf_node) for one game.  Stages (index, N, Q) of every node on the path in LDS.
+// What the last level of a walk looked at, for the speculation of a parked leaf's siblings (below): the position the last move
+// was made from, that node's child count, the lane that won the arg-max, and this lane's own child record.
 template <class G>
+struct WalkTail {
+    typename G::State before;
+    u32 k, n, link;
+    int best;
+};
+template <class G, bool TAIL = false>
 __device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State& s, u32 root, u32 rN, float rQ,
-                            u32 rlink, int gl, u32* p_idx, u32* p_N, float* p_Q) {
+                            u32 rlink, int gl, u32* p_idx, u32* p_N, float* p_Q, WalkTail<G>* tail = nullptr) {
     constexpr int LG = G::LG;
     u32 node = root, Np = rN, link = rlink;
     int depth = 0, hint = 0;
@@ -211,6 +219,13 @@ __device__ inline Leaf walk(const Dev& d, const uint4* nodes, typename G::State&
             p_Q[depth] = as_f(cQ);
         }
         hint = G::move_hint(s);
+        if constexpr (TAIL) {
+            tail->before = s;
+            tail->k = k;
+            tail->n = rec.x;
+            tail->link = rec.w;
+            tail->best = best;
+        }
         G::step(s, (int)link_action(cl));  // env.step(action), redundantly on every lane of the group
         Np = cN;
         link = cl;
@@ -367,6 +382,64 @@ __device__ inline void cache_insert(const Dev& d, u64 w0, u64 w1, const float* p
     else if (gl == 2) a = as_u(probs[2]), b = as_u(probs[3]), c = as_u(probs[4]);
     else a = as_u(probs[5]), b = as_u(probs[6]), c = as_u(value);
     d.cache[(kh & d.cache_mask) * 4 + gl] = make_uint4(a, b, c, cache_tag(kh, a, b, c, (u32)gl));
+}
+
+// the same by ONE lane (speculative rows: every lane has a row of its own)
+__device__ inline void cache_insert_lane(const Dev& d, u64 w0, u64 w1, const float* probs, float value) {
+    const u64 kh = cache_hash(d, w0, w1);
+    uint4* e = d.cache + (kh & d.cache_mask) * 4;
+    const u32 x[12] = {(u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32), as_u(probs[0]), as_u(probs[1]),
+                       as_u(probs[2]), as_u(probs[3]), as_u(probs[4]), as_u(probs[5]), as_u(probs[6]), as_u(value)};
+#pragma unroll
+    for (u32 i = 0; i < 4; i++) e[i] = make_uint4(x[3 * i], x[3 * i + 1], x[3 * i + 2], cache_tag(kh, x[3 * i], x[3 * i + 1], x[3 * i + 2], i));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Speculation (az_search of a handful of games: the drop-in player's single game).  One game keeps one workgroup of K3 busy
+// and 255 CUs idle, and a search's next new leaves are no secret: unvisited children are tried in insertion order before any
+// revisit (first-play urgency, MCTS.py:50-51,80), so when a leaf has to wait for the network its unvisited SIBLINGS are for
+// certain the next new leaves of its parent, and its own CHILDREN the next new leaves below it.  Their positions -- in both
+// orientations, the flip bit of a future playout is not known -- ride along in the same K3 launch on rows of their own
+// (Dev::spec_rows rows behind the slots' rows: kind x lane x orientation), and the next tree step stores the answers in the
+// evaluation cache, where the later playouts find them.  Only the table is written: no game's tree, counters or random streams
+// are touched, so the search is the same bit for bit with speculation on or off (K3's result for a position does not depend
+// on the launch it was evaluated in).  Positions that are terminal or already in the table are skipped.
+// ------------------------------------------------------------------------------------------------------------
+template <class G>
+__device__ inline void spec_flush(const Dev& d, int g, int gl) {   // K3 has answered the rows marked by the previous tree step
+    if constexpr (G::GAME == AZ_GAME_C4) {
+        for (int r = gl; r < d.spec_rows; r += G::LG) {
+            const i64 m = (i64)g * d.spec_rows + r;
+            if (!d.spec_mark[m]) continue;
+            const i64 v = (i64)d.G + m;
+            float pr[G::A];
+#pragma unroll
+            for (int a = 0; a < G::A; a++) pr[a] = d.eval_probs[v * G::A + a];
+            cache_insert_lane(d, d.leaf_state[v * G::W], d.leaf_state[v * G::W + 1], pr, d.eval_value[v]);
+            d.spec_mark[m] = 0;
+        }
+    }
+}
+template <class G>
+__device__ inline void spec_row(const Dev& d, int g, int gl, int kind, const typename G::State& from, int action) {
+    if constexpr (G::GAME == AZ_GAME_C4) {
+        typename G::State t = from;
+        const int hint = G::move_hint(t);
+        G::step(t, action);
+        if (G::winner_moved(t, hint) != 0 || G::full(t)) return;   // terminal leaves never reach the network
+        const bool sym = G::symmetric(t);
+        for (int o = 0; o < (sym ? 1 : 2); o++) {                   // the mirror image of a symmetric board is the board
+            const typename G::State aug = o ? G::flip(t) : t;
+            float pr[G::A], val;
+            if (cache_probe(d, aug.w[0], aug.w[1], pr, val)) continue;
+            const i64 m = (i64)g * d.spec_rows + (kind * G::LG + gl) * 2 + o, v = (i64)d.G + m;
+#pragma unroll
+            for (int i = 0; i < G::W; i++) d.leaf_state[v * G::W + i] = aug.w[i];
+            d.spec_mark[m] = 1;
+            const u32 pos = atomicAdd(d.eval_count, 1u);
+            d.eval_list[pos] = (u32)v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -618,12 +691,16 @@ __device__ inline void roll_playout_done(const Dev& d, const Roll& r, int g, int
 // slowest game).  The game's state -- root position, root statistics, allocation mark, counters -- lives in registers from
 // one playout to the next (as in the fused kernel) and goes back to memory at a ply end and at the end of the round: a
 // playout's dependent chain is then the walk itself plus one table probe.
-template <class G>
+template <class G, bool SPEC = false>
 __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int gl, u32* p_idx, u32* p_N, float* p_Q, Cnt& cnt,
                                         u64 t_start) {
     constexpr int LG = G::LG;
     // an idle slot (parked, or its game is over and was not refilled) is left exactly as it is -- a parked leaf stays parked
     if (!d.active[g]) return;
+    if constexpr (SPEC) {
+        spec_flush<G>(d, g, gl);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     uint4* nodes = d.nodes + (i64)g * d.cap;
     typename G::State rs = load_root_state<G>(d, g);
     u32 root = d.root[g], nalloc = d.n_alloc[g], fpos = d.flip_pos[g];
@@ -642,7 +719,8 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
         // playouts run in which round changes nothing in any game: each game's playouts follow one another all the same)
         if (it > 0 && r.budget && __builtin_amdgcn_s_memrealtime() - t_start > (u64)r.budget) break;
         typename G::State s = rs;   // env.copy()
-        Leaf lf = walk<G>(d, nodes, s, root, rN, rQ, rlink, gl, p_idx, p_N, p_Q);
+        WalkTail<G> tail;
+        Leaf lf = walk<G, SPEC>(d, nodes, s, root, rN, rQ, rlink, gl, p_idx, p_N, p_Q, &tail);
         typename G::State aug;
         leaf_prepare<G>(d, g, s, aug, lf, fpos, ctr);
         float probs[G::A], cvalue = 0.f;
@@ -666,6 +744,11 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
                 d.leaf_tvalue[g] = lf.tvalue;
                 u32 pos = atomicAdd(d.eval_count, 1u);
                 d.eval_list[pos] = (u32)g;
+            }
+            if constexpr (SPEC) {   // the leaf's unvisited siblings and its own children ride along (Speculation, above)
+                if (lf.depth > 0 && (u32)gl < tail.k && gl != tail.best && tail.n == 0u)
+                    spec_row<G>(d, g, gl, 0, tail.before, (int)link_action(tail.link));
+                if (gl < G::A && ((G::legal(s) >> gl) & 1u)) spec_row<G>(d, g, gl, 1, s, gl);
             }
             parked = true;
             break;
@@ -742,7 +825,7 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
 // GPW: games per wavefront (64 / LG fills every lane).  A wave runs the union of its games' paths -- the deepest walk, every
 // branch any of them takes, as many in-place playouts as its busiest game -- so with fewer games per wave each game waits
 // for fewer others; the tree step is far from filling the chip (2 048 games are 256 full waves), so the extra waves are free.
-template <class G, int BS, int GPW = 64 / G::LG>
+template <class G, int BS, int GPW = 64 / G::LG, bool SPEC = false>
 __device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clear_count, const Roll& r) {
     constexpr int LG = G::LG, GPB = (BS / 64) * GPW;
     static_assert(GPW * LG <= 64, "lane groups of one wave");
@@ -764,7 +847,7 @@ __device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clea
     if (r.on) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (played) roll_playout_done<G>(d, r, g, gl);
-        if (mode & 2) select_body_roll<G>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt, t_start);
+        if (mode & 2) select_body_roll<G, SPEC>(d, r, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt, t_start);
     } else if (mode & 2) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         select_body<G>(d, g, gl, s_idx[grp], s_N[grp], s_Q[grp], cnt);
@@ -774,6 +857,10 @@ __device__ __forceinline__ void tree_step_body(const Dev& d, int mode, u32* clea
 template <class G, int BS, int GPW = 64 / G::LG>
 __global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
     tree_step_body<G, BS, GPW>(d, mode, clear_count, r);
+}
+// az_search of a handful of Connect4 games with speculative rows (one game per wave: nobody's walk waits for a neighbour's probes)
+__global__ __launch_bounds__(256) void k_tree_step_spec(Dev d, int mode, u32* clear_count, Roll r) {
+    tree_step_body<C4, 256, 1, true>(d, mode, clear_count, r);
 }
 template <class G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tree_step_small(Dev d, int mode, u32* clear_count,
@@ -1115,6 +1202,12 @@ static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_
     Roll r;
     memset(&r, 0, sizeof(r));
     if (roll) r = *roll;
+    if (r.on && r.search && d.spec_rows && d.cache && game_of(d) == AZ_GAME_C4) {
+        constexpr int gpb = 256 / 64;   // one game per wave
+        k_tree_step_spec<<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count, r);
+        AZ_HIP(hipGetLastError());
+        return AZ_OK;
+    }
     AZ_DISPATCH_GAME(game_of(d), {
         static const char* shape = getenv("AZ_TREE_STEP");   // "big" / "small": measurement hook
         // with the evaluation cache a launch runs several playouts per game and K3 launches no longer fill the chip: the big

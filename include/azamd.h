@@ -175,9 +175,11 @@ int az_set_flip_stream(az_engine *e, const uint8_t *bits, int64_t n_per_game);
 /* ---- K2 (+K3): search ----------------------------------------------------------------------------------- */
 /* n_sims playouts for every slot: MCTS_AZ.get_action_visits' loop (MCTS.py:166-169), evaluator on device.
  * n_sims <= 0 uses cfg.n_playout.  Asynchronous on the engine stream (az_get_* calls synchronise), except for
- * AZ_EVAL_CNN engines of <= 32 slots -- the drop-in player's single game -- where playouts that need no network
- * evaluation (terminal node, position in the evaluation cache) are finished in place and the call returns when the
- * search is complete; the trees are the same bit for bit either way.  AZ_ERR_STATE while rolling self-play
+ * AZ_EVAL_CNN engines of <= 512 slots with the evaluation cache (<= 32 without) -- first of all the drop-in player's
+ * single game -- where playouts that need no network evaluation (terminal node, position in the evaluation cache)
+ * are finished in place, a leaf that waits for the network takes its unvisited siblings and its children along into
+ * the same K3 launch (their answers go into the cache, where the next playouts find them), and the call returns when
+ * the search is complete; the trees are the same bit for bit either way.  AZ_ERR_STATE while rolling self-play
  * (az_selfplay_rounds) is in progress on the engine: az_reset_games / az_set_roots first. */
 int az_search(az_engine *e, int32_t n_sims);
 /* AZ_EVAL_HOST: one playout for every slot in two halves.  az_select walks to a leaf (MCTS.py:141-144) and

@@ -281,10 +281,12 @@ def test_rolling_time_budget_changes_nothing_in_any_game():
 
 # ------------------------------------------------------------------------------------------------ az_search, rolling form
 def test_az_search_rolling_form_grows_the_same_trees():
-    """az_search on an AZ_EVAL_CNN engine of a handful of games runs on the rolling tree step (terminal playouts and cache hits
-    finished in place, a round only for leaves the network has to see); larger engines keep the lockstep chain.
-    AZ_SEARCH_ROLL=0|1 forces one form for every size (read once per process): both must grow the same trees -- actions,
-    visit counts, Q and prior bit patterns of every root, and the moves played -- for 1, 5 and 200 games, eval and train mode."""
+    """az_search on an AZ_EVAL_CNN engine of up to 512 games runs on the rolling tree step (terminal playouts and cache hits
+    finished in place, a round only for leaves the network has to see) and takes a waiting leaf's unvisited siblings and its
+    children along into the K3 launch (speculative rows: their answers go into the evaluation cache); larger engines keep
+    the lockstep chain.  AZ_SEARCH_ROLL=0|1 forces one form for every size, AZ_SPEC=0 switches the speculation off (read once
+    per process): all must grow the same trees -- actions, visit counts, Q and prior bit patterns of every root, and the
+    moves played -- for 1, 5, 200 and 600 games (600: two cohorts), eval and train mode."""
     import hashlib
     import subprocess
     import sys
@@ -294,7 +296,7 @@ def test_az_search_rolling_form_grows_the_same_trees():
         "from alphazero_amd.engine import SelfPlayEngine\n"
         "blob = np.fromfile(%r, dtype='<f4')\n"
         "h = hashlib.sha256()\n"
-        "for G, S, noise, plies in ((1, 300, 0.0, 12), (5, 120, 0.7, 10), (200, 64, 0.7, 6)):\n"
+        "for G, S, noise, plies in ((1, 300, 0.0, 12), (5, 120, 0.7, 10), (200, 64, 0.7, 6), (600, 40, 0.0, 4)):\n"
         "    e = SelfPlayEngine('Connect4', n_games=G, n_playout=S, c_puct=1.25, evaluator='cnn', flip='random', reuse_tree=True,\n"
         "                       dirichlet_alpha=noise, rng_seed=11, move='sample')\n"
         "    e.load_net(blob)\n"
@@ -313,12 +315,13 @@ def test_az_search_rolling_form_grows_the_same_trees():
         "    e.close()\n"
         "print(h.hexdigest())\n" % (ROOT, os.path.join(G, "weights", "AZ_Connect4_CNN_current.f32")))
     res = {}
-    for name, env in (("chain", dict(AZ_SEARCH_ROLL="0")), ("rolling", dict(AZ_SEARCH_ROLL="1")), ("default", {})):
-        e = {k: v for k, v in os.environ.items() if k != "AZ_SEARCH_ROLL"}
+    for name, env in (("chain", dict(AZ_SEARCH_ROLL="0")), ("rolling", dict(AZ_SEARCH_ROLL="1", AZ_SPEC="0")),
+                      ("speculating", dict(AZ_SEARCH_ROLL="1", AZ_SPEC_MAX_G="4096")), ("default", {})):
+        e = {k: v for k, v in os.environ.items() if k not in ("AZ_SEARCH_ROLL", "AZ_SPEC", "AZ_SPEC_MAX_G")}
         p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
         assert p.returncode == 0, (name, p.stderr.decode()[-1500:])
         res[name] = p.stdout.decode().strip().splitlines()[-1]
-    assert res["chain"] == res["rolling"] == res["default"], res
+    assert res["chain"] == res["rolling"] == res["speculating"] == res["default"], res
 
 
 # ------------------------------------------------------------------------------------------------ evaluation cache
