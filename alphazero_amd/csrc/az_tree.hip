@@ -433,6 +433,7 @@ __device__ inline void spec_row(const Dev& d, int g, int gl, int kind, const typ
             float pr[G::A], val;
             if (cache_probe(d, aug.w[0], aug.w[1], pr, val)) continue;
             const i64 m = (i64)g * d.spec_rows + (kind * G::LG + gl) * 2 + o, v = (i64)d.G + m;
+            if (d.spec_mark[m]) continue;   // taken (cannot happen with one parked leaf per game and round; the list must never overflow)
 #pragma unroll
             for (int i = 0; i < G::W; i++) d.leaf_state[v * G::W + i] = aug.w[i];
             d.spec_mark[m] = 1;
