@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 3: one GPU-box session that produces what profiles/r03_* keeps.  Every rocprofv3 pass is a run of its own (PMC
 # passes are never combined with tracing), every step has its own time limit, and the script stops at the first failure.
-# Usage (on the GPU box, from the repo root): bash tools/gpu_profile_r03.sh [part]    part: bench | cfg4 | tree | shape | all
+# Usage (on the GPU box, from the repo root): bash tools/gpu_profile_r03.sh [part]    part: bench | cfg3 | cfg4 | tree | shape | all
 set -uo pipefail
 PART=${1:-all}
 O=gpurun_out/prof_r03
@@ -22,6 +22,11 @@ if [ $PART = bench ] || [ $PART = all ]; then
   run timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/bench_fetch -o pmc -- $P > $O/bench_fetch.log 2>&1
   run timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $O/bench_write -o pmc -- $P > $O/bench_write.log 2>&1
   run timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/bench_sq -o pmc -- $P > $O/bench_sq.log 2>&1
+fi
+if [ $PART = cfg3 ] || [ $PART = all ]; then
+  C3="python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-second-leg --mean-plies 33.2 --preroll 10"
+  run timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $O/cfg3 -o bench -- $C3 > $O/cfg3_stats.log 2>&1
+  grep '"metric"' $O/cfg3_stats.log > $O/cfg3_line.json
 fi
 if [ $PART = cfg4 ] || [ $PART = all ]; then
   C="python3 bench.py --config 4 --steps 6 --warmup 2 --no-cpu-baseline --mean-plies 41.1 --preroll 48"

@@ -76,6 +76,20 @@ def bench():
         sq_row(f, "k_tree_step<C4,512,2> (bench)", db, "k_tree_step")
 
 
+def cfg3():
+    if not os.path.isdir(os.path.join(O, "cfg3")):
+        return
+    with open(os.path.join(T, "r03_cfg3_kernel_stats.txt"), "w") as f:
+        cmd = "python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-second-leg --mean-plies 33.2 --preroll 10"
+        f.write("# BASELINE configs[3], one GPU's share (16 384 slots, 2^30-entry evaluation cache, 4 cohorts of 4 096 games, time budget 296 us)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- %s\n" % cmd)
+        db = os.path.join(O, "cfg3", "bench_results.db")
+        f.write(cap(rs.kernel_stats, db))
+        f.write("## one round of a cohort on its HIP stream over the last 20 % of the trace (the timed steps)\n")
+        f.write(cap(rs.chain_stats, db, 0.2))
+        f.write("## bench.py JSON line of this (profiled) run:\n" + open(os.path.join(O, "cfg3_line.json")).read())
+
+
 def cfg4():
     if not os.path.isdir(os.path.join(O, "cfg4")):
         return
@@ -133,7 +147,7 @@ def shape():
 
 if __name__ == "__main__":
     os.makedirs(T, exist_ok=True)
-    for part in (bench, cfg4, tree, shape):
+    for part in (bench, cfg3, cfg4, tree, shape):
         print("make_profiles_r03:", part.__name__, flush=True)
         part()
     print("wrote", sorted(os.listdir(T)))
