@@ -932,7 +932,7 @@ int az_set_flip_stream(az_engine* e, const uint8_t* bits, int64_t n_per_game) {
 // The engine's slots cut into its C cohorts: per cohort a view of the device state for each of the two leaf counters that
 // successive rounds alternate between, and the stream its chain runs on (cohort 0 rides on the engine stream: a process has
 // few hardware queues).
-static void cohort_views(const az_engine* e, Dev (*dc)[2], hipStream_t* cs) {
+static void cohort_views(const az_engine* e, Dev (*dc)[2], hipStream_t* cs, bool speculating = false) {
     const Dev& d = e->d;
     const int C = e->C;
     for (int c = 0; c < C; c++) {
@@ -943,6 +943,8 @@ static void cohort_views(const az_engine* e, Dev (*dc)[2], hipStream_t* cs) {
             dc[c][par].gn = (i32)(hi - lo);
             dc[c][par].eval_count = d.eval_count + 4 * c + par;
             dc[c][par].eval_list = d.eval_list + lo * (1 + d.spec_rows);   // a cohort's list holds its slots' rows and their speculative rows
+            // only az_search's rolling form speculates: everywhere else a K3 launch is sized for the slots' own rows
+            if (!speculating) dc[c][par].spec_rows = 0;
         }
         cs[c] = c == 0 ? e->stream : e->cstream[c];
     }
@@ -960,7 +962,7 @@ static int search_cnn_rolling(az_engine* e, int n_sims) {
     const int C = e->C;
     Dev dc[AZ_MAX_COHORTS][2];
     hipStream_t cs[AZ_MAX_COHORTS];
-    cohort_views(e, dc, cs);
+    cohort_views(e, dc, cs, true);
     if (!e->search_cnt) AZ_TRY(e->dalloc(&e->search_cnt, 2));
     AZ_HIP(hipMemsetAsync(e->search_cnt, 0, 2 * sizeof(u32), e->stream));
     AZ_HIP(hipMemsetAsync(d.move_sims, 0, (size_t)d.G * sizeof(i32), e->stream));
