@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "az_cnn.hpp"
@@ -590,8 +591,14 @@ int cnn_forward(Cnn* c, i64 n, const u64* states_dev, float* logp, float* logv, 
 
 int cnn_eval_leaves(Cnn* c, const Dev& d, hipStream_t st) {
     const unsigned max_n = (unsigned)d.gn * (unsigned)(1 + d.spec_rows);   // the cohort's slots (and their speculative rows) bound its leaf count
-    if (c->split)
-        return cnns_launch(c->split, max_n, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr, d.eval_probs, d.eval_value, st);
+    if (c->split) {
+        // with speculative rows the capacity is 33 rows per game and the usual fill a handful: one workgroup per CU (fewer for
+        // a handful of games), or workgroups for four rows per game if that is more (at most 768), stride over what the launch holds
+        unsigned cap = 0;
+        if (d.spec_rows) cap = d.gn <= 8 ? (unsigned)(17 * d.gn) : (unsigned)std::min(std::max((d.gn * 4 + 2) / 3, 256), 768);
+        return cnns_launch(c->split, max_n, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr, d.eval_probs, d.eval_value, st,
+                           cap);
+    }
     if (c->wino)
         return cnnw_launch(c->wino, max_n, 0, d.eval_count, d.eval_list, d.leaf_state, nullptr, nullptr, d.eval_probs, d.eval_value, st);
     const unsigned grid = (max_n + SPB - 1) / SPB;

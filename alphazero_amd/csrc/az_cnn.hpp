@@ -35,8 +35,9 @@ int cnnw_launch(CnnW* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32
 
 int cnns_create(const float* blob, size_t n_floats, CnnS** out);
 void cnns_destroy(CnnS* c);
+// grid_cap != 0: the launch may use a grid of that many workgroups that stride over the batch (capacity far above the usual fill)
 int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
-                float* logv, float* probs, float* value, hipStream_t st);
+                float* logv, float* probs, float* value, hipStream_t st, unsigned grid_cap = 0);
 
 // ---- reference state_dict blob walking + eval-mode BatchNorm folding (Network.py:19-24,33-51) ----
 constexpr float CNN_BN_EPS = 1e-5f;  // torch.nn.BatchNorm2d default

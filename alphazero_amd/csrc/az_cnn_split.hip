@@ -327,12 +327,13 @@ __device__ inline void store_image(_Float16* hi, _Float16* lo, const int (&crow)
 //   <3, 4>  one workgroup per CU, 126 cells on 128 columns (1.6 % of the MFMA work on padding columns instead of 12.5 %): wave tile
 //           64 channels x 64 cells; a third more weight bytes per position
 //   <4, 8>  one workgroup of 8 waves (32 x 96 tiles): kept for measurement; all waves share the barriers, so nothing overlaps
+// the workgroup's whole pass over the NS positions that start at batch index s0 (a `return` ends the pass of the wave that takes it)
 template <int NS, int NW>
-__global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
-                                                              const u32* __restrict__ list, const u64* __restrict__ states,
-                                                              float* __restrict__ logp, float* __restrict__ logv,
-                                                              float* __restrict__ probs, float* __restrict__ value, int desync,
-                                                              u32 max_n) {
+__device__ __forceinline__ void split_pass(const CnnSDev& w, i64 n_host, const u32* __restrict__ n_ptr,
+                                           const u32* __restrict__ list, const u64* __restrict__ states,
+                                           float* __restrict__ logp, float* __restrict__ logv,
+                                           float* __restrict__ probs, float* __restrict__ value, int desync,
+                                           u32 max_n, const i64 s0) {
     extern __shared__ _Float16 lds[];
     constexpr int SNS = NS, SCELLS = NS * 42, SROWS = srows(NS);
     __shared__ float hb[4][SCELLS];  // head activations: 3 policy channels, 1 value channel
@@ -341,7 +342,6 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
     __shared__ u32 s_amax[7][SNS];   // per layer output and position: bits of the largest |activation| (ds_max_u32)
     _Float16* hi = lds;
     _Float16* lo = lds + SROWS * SRS;
-    const i64 s0 = (i64)blockIdx.x * SNS;
     // waves along cells / channels; 32-cell and 32-channel fragments per wave
     constexpr int NWB = NS == 2 ? 1 : 2, SNF = NS == 3 ? 2 : 3, NWA = NW / NWB, SMF = 4 / NWA;
     constexpr int NST = 2;                 // operand register sets (a third, tried on the 64 x 64 tile, measured within noise)
@@ -636,6 +636,28 @@ __global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(
         if (value) value[slot] = (-s_player[s]) * 0.5f * v0 + v1 - v2;
     }
     STAMP(31);   // this wave's end
+}
+template <int NS, int NW>
+__global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split(CnnSDev w, i64 n_host, const u32* __restrict__ n_ptr,
+                                                              const u32* __restrict__ list, const u64* __restrict__ states,
+                                                              float* __restrict__ logp, float* __restrict__ logv,
+                                                              float* __restrict__ probs, float* __restrict__ value, int desync,
+                                                              u32 max_n) {
+    split_pass<NS, NW>(w, n_host, n_ptr, list, states, logp, logv, probs, value, desync, max_n, (i64)blockIdx.x * NS);
+}
+// The same with a grid SMALLER than the batch may need: a workgroup takes every gridDim.x-th group of NS positions.  For launches
+// whose capacity is far above what they usually hold (speculative rows: 33 rows per game, a handful filled): a workgroup that
+// finds nothing to do still costs the dispatcher ~0.1 us, in sequence, and thousands of them cost more than the launch's work
+// (rolling self-play at 256 slots: 2 816 workgroups for ~80 rows, 140 us per launch instead of 70).
+template <int NS, int NW>
+__global__ __launch_bounds__(NW * 64, NS == 2 ? 2 : 1) void k_cnn_forward_split_strided(CnnSDev w, const u32* __restrict__ n_ptr,
+                                                              const u32* __restrict__ list, const u64* __restrict__ states,
+                                                              float* __restrict__ probs, float* __restrict__ value, u32 max_n) {
+    const i64 n = (i64)(*n_ptr);
+    for (i64 s0 = (i64)blockIdx.x * NS; s0 < n; s0 += (i64)gridDim.x * NS) {
+        split_pass<NS, NW>(w, 0, n_ptr, list, states, nullptr, nullptr, probs, value, 0, max_n, s0);
+        __syncthreads();   // the pass's last readers of the head activations and slot numbers, before the next pass's writers
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ 16x16x32 form
@@ -1127,6 +1149,10 @@ int cnns_create(const float* blob, size_t n_floats, CnnS** out) {
                                             (int)split_lds(2)) != hipSuccess ||
                         hipFuncSetAttribute((const void*)k_cnn_forward_split<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)split_lds(3)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split_strided<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(3)) != hipSuccess ||
+                        hipFuncSetAttribute((const void*)k_cnn_forward_split_strided<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)split_lds(2)) != hipSuccess ||
                         hipFuncSetAttribute((const void*)k_cnn_forward_split16, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)split_lds(3)) != hipSuccess)) {
         set_error("hipFuncSetAttribute(k_cnn_forward_split, dynamic LDS) failed");
@@ -1153,8 +1179,22 @@ void cnns_destroy(CnnS* c) {
 }
 
 int cnns_launch(CnnS* c, unsigned max_n, i64 n_host, const u32* n_ptr, const u32* list, const u64* states, float* logp,
-                float* logv, float* probs, float* value, hipStream_t st) {
+                float* logv, float* probs, float* value, hipStream_t st, unsigned grid_cap) {
     if (max_n == 0) return AZ_OK;
+    // a launch whose capacity (max_n) is far above what it usually holds: a grid of grid_cap workgroups that stride over the batch
+    static const char* stride_env = getenv("AZ_K3_STRIDE");   // "0": off (A/B)
+    if (grid_cap && n_ptr && !logp && !logv && !getenv("AZ_K3_SPLIT_CFG") && !(stride_env && atoi(stride_env) == 0)) {
+        if (grid_cap <= 32 && (max_n + 1) / 2 > grid_cap) {   // a handful of games: the two-position form (one workgroup alone: 52 us)
+            k_cnn_forward_split_strided<2, 4><<<dim3(grid_cap), dim3(256), split_lds(2), st>>>(c->d, n_ptr, list, states, probs, value, max_n);
+            AZ_HIP(hipGetLastError());
+            return AZ_OK;
+        }
+        if (grid_cap > 32 && (max_n + 2) / 3 > grid_cap) {
+            k_cnn_forward_split_strided<3, 4><<<dim3(grid_cap), dim3(256), split_lds(3), st>>>(c->d, n_ptr, list, states, probs, value, max_n);
+            AZ_HIP(hipGetLastError());
+            return AZ_OK;
+        }
+    }
     static const char* cfg = getenv("AZ_K3_SPLIT_CFG");   // tuning hook: "44" (4 positions, 4 waves), "48", "24"
     // A launch of a few leaves (the drop-in player's single game: one leaf) is ONE workgroup's latency whatever the form, and the
     // two-position form's workgroup is the shortest (one workgroup alone: 52 us against 65 us for <3,4> and 95 us for <4,4>).  All

@@ -552,10 +552,11 @@ int az_engine_create(const az_config* cfg, az_engine** out) {
         // 512: 38.0 -> 31.5, 1 024: 40.4 -> 46.0 (a K3 launch carries up to 33 rows per game: from a thousand games on the extra rows
         // cost more CU time than the rounds they save), 2 048: 84.7 -> 83.5
         static const char* specg_env = getenv("AZ_SPEC_MAX_G");   // measurement hook
-        const int spec_max_g = specg_env ? atoi(specg_env) : 512;
+        const int spec_max_g = specg_env ? atoi(specg_env) : 1024;
         d.spec_rows = (cfg->evaluator == AZ_EVAL_CNN && cfg->game == AZ_GAME_C4 && G <= spec_max_g && cache_wanted &&
                        !(spec_env && atoi(spec_env) == 0)) ? 32 : 0;
         d.spec_mark = nullptr;
+        d.spec_tag = 1;
     }
     const i64 rows = (i64)G * (1 + d.spec_rows);
     A_(d.leaf_state, rows * gi.W);
@@ -882,6 +883,8 @@ int az_reset_games(az_engine* e) {
     e->roll_started = false;
     e->roll_par = 0;
     AZ_HIP(hipMemsetAsync(d.eval_count, 0, 16 * AZ_MAX_COHORTS, e->stream));
+    // leaves that were waiting for the network are dropped with their lists: so are the speculative rows that waited with them
+    if (d.spec_rows) AZ_HIP(hipMemsetAsync(d.spec_mark, 0, (size_t)d.G * d.spec_rows, e->stream));
     AZ_HIP(hipMemsetAsync(d.err, 0, sizeof(u32), e->stream));
     AZ_HIP(hipMemsetAsync(d.root_state, 0, (size_t)d.G * d.W * sizeof(u64), e->stream));
     AZ_TRY(launch_init_slots(d, e->cfg.game == AZ_GAME_NBTTT ? 1 : 0, e->cfg.game_id_base, e->stream));
@@ -898,6 +901,8 @@ int az_set_roots(az_engine* e, const uint64_t* states) {
     e->roll_started = false;
     e->roll_par = 0;
     AZ_HIP(hipMemsetAsync(d.eval_count, 0, 16 * AZ_MAX_COHORTS, e->stream));
+    // leaves that were waiting for the network are dropped with their lists: so are the speculative rows that waited with them
+    if (d.spec_rows) AZ_HIP(hipMemsetAsync(d.spec_mark, 0, (size_t)d.G * d.spec_rows, e->stream));
     AZ_HIP(hipMemcpyAsync(d.root_state, states, (size_t)d.G * d.W * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     AZ_TRY(launch_init_slots(d, 0, e->cfg.game_id_base, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
@@ -965,6 +970,7 @@ static int search_cnn_rolling(az_engine* e, int n_sims) {
     cohort_views(e, dc, cs, true);
     if (!e->search_cnt) AZ_TRY(e->dalloc(&e->search_cnt, 2));
     AZ_HIP(hipMemsetAsync(e->search_cnt, 0, 2 * sizeof(u32), e->stream));
+    if (d.spec_rows) AZ_HIP(hipMemsetAsync(d.spec_mark, 0, (size_t)d.G * d.spec_rows, e->stream));
     AZ_HIP(hipMemsetAsync(d.move_sims, 0, (size_t)d.G * sizeof(i32), e->stream));
     auto fork = [&]() -> int {
         if (C > 1) {
@@ -1243,7 +1249,10 @@ int az_selfplay_rounds(az_engine* e, int32_t n_rounds, double temp, int32_t firs
     const int C = e->C, S = e->cfg.n_playout;
     Dev dc[AZ_MAX_COHORTS][2];
     hipStream_t cs[AZ_MAX_COHORTS];
-    cohort_views(e, dc, cs);
+    // speculative rows (az_tree.hip "Speculation") also in rolling self-play while the chip has CUs to spare (launch_roll_step has
+    // the numbers: +50 % and more up to 512 slots, +14 % at 1 024, a loss at 2 048)
+    static const char* srg_env = getenv("AZ_SPEC_ROLL_MAX_G");   // measurement hook
+    cohort_views(e, dc, cs, d.G <= (srg_env ? atoi(srg_env) : 1024));
     if (C > 1) {
         AZ_HIP(hipEventRecord(e->ev_fork, e->stream));
         for (int c = 1; c < C; c++) AZ_HIP(hipStreamWaitEvent(cs[c], e->ev_fork, 0));
@@ -1446,6 +1455,9 @@ int az_net_load(az_engine* e, const float* blob, size_t n_floats) {
     // The epoch is folded into the entries' tags, so none of them validates any more; nothing is cleared.
     e->cache_loads++;
     e->d.cache_epoch = mix64(0xA24BAED4963EE407ull + e->cache_loads * 0x9FB21C651E98DF25ull + (u64)(uintptr_t)e);
+    // speculative rows marked under the previous weights and not yet stored (still on a list, or a slot parked by az_set_active) must
+    // not enter the table under the new epoch: a row's mark is the tag of the weights it was marked under
+    e->d.spec_tag = (u8)(1 + e->cache_loads % 250);
     return AZ_OK;
 }
 

@@ -71,7 +71,8 @@ struct Dev {
     // speculative evaluation (az_search of a handful of games, az_tree.hip "Speculation"): spec_rows extra rows per slot behind the
     // G slot rows of leaf_state / eval_probs / eval_value / eval_list (row G + g * spec_rows + r), 0 = off
     i32 spec_rows;
-    u8* spec_mark;        // [G][spec_rows] 1 = the row holds a position whose evaluation goes into the cache at the next tree step
+    u8* spec_mark;        // [G][spec_rows] != 0: the row holds a position whose evaluation goes into the cache at the next tree step
+    u8 spec_tag;          // what a mark is set to: changes with every az_net_load (a row marked under other weights is dropped)
     // status
     i8* winner;           // [G]
     u8* done;             // [G]

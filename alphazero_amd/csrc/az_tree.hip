@@ -410,12 +410,15 @@ __device__ inline void spec_flush(const Dev& d, int g, int gl) {   // K3 has ans
     if constexpr (G::GAME == AZ_GAME_C4) {
         for (int r = gl; r < d.spec_rows; r += G::LG) {
             const i64 m = (i64)g * d.spec_rows + r;
-            if (!d.spec_mark[m]) continue;
-            const i64 v = (i64)d.G + m;
-            float pr[G::A];
+            const u8 mark = d.spec_mark[m];
+            if (!mark) continue;
+            if (mark == d.spec_tag) {   // (else: marked under weights that have been replaced since)
+                const i64 v = (i64)d.G + m;
+                float pr[G::A];
 #pragma unroll
-            for (int a = 0; a < G::A; a++) pr[a] = d.eval_probs[v * G::A + a];
-            cache_insert_lane(d, d.leaf_state[v * G::W], d.leaf_state[v * G::W + 1], pr, d.eval_value[v]);
+                for (int a = 0; a < G::A; a++) pr[a] = d.eval_probs[v * G::A + a];
+                cache_insert_lane(d, d.leaf_state[v * G::W], d.leaf_state[v * G::W + 1], pr, d.eval_value[v]);
+            }
             d.spec_mark[m] = 0;
         }
     }
@@ -436,7 +439,7 @@ __device__ inline void spec_row(const Dev& d, int g, int gl, int kind, const typ
             if (d.spec_mark[m]) continue;   // taken (cannot happen with one parked leaf per game and round; the list must never overflow)
 #pragma unroll
             for (int i = 0; i < G::W; i++) d.leaf_state[v * G::W + i] = aug.w[i];
-            d.spec_mark[m] = 1;
+            d.spec_mark[m] = d.spec_tag;
             const u32 pos = atomicAdd(d.eval_count, 1u);
             d.eval_list[pos] = (u32)v;
         }
@@ -645,6 +648,8 @@ struct Roll {
     u32 budget;    // 0, or: no further in-place playout is started once the launch is this many 10 ns ticks old
     int search;    // az_search on the rolling step: a game stops after its S playouts (no ply end).  2: the first selection
     u32* search_cnt;   // search: [0] games that take part, [1] games whose S playouts are complete
+    int spec_width;    // speculation: how many of a waiting leaf's next siblings, and of its first children, ride along
+    int spec_kinds;    // bit 0: siblings, bit 1: children
     int S;         // playouts per move
     int first_n;   // game.py:41 temperature schedule (<0: temp for every ply)
     int move_mode, reuse;
@@ -747,9 +752,17 @@ __device__ inline void select_body_roll(const Dev& d, const Roll& r, int g, int 
                 d.eval_list[pos] = (u32)g;
             }
             if constexpr (SPEC) {   // the leaf's unvisited siblings and its own children ride along (Speculation, above)
-                if (lf.depth > 0 && (u32)gl < tail.k && gl != tail.best && tail.n == 0u)
+                // ... the next r.spec_width of each, in the order in which the search will ask for them: children are visited in
+                // insertion order (the unvisited ones are the tail of the parent's array; the leaf's own children will be inserted
+                // in ascending order of the EVALUATED position's actions, i.e. descending when this playout's board is mirrored)
+                if ((r.spec_kinds & 1) && lf.depth > 0 && (u32)gl < tail.k && gl > tail.best && gl <= tail.best + r.spec_width && tail.n == 0u)
                     spec_row<G>(d, g, gl, 0, tail.before, (int)link_action(tail.link));
-                if (gl < G::A && ((G::legal(s) >> gl) & 1u)) spec_row<G>(d, g, gl, 1, s, gl);
+                const u32 legal = G::legal(s);
+                if ((r.spec_kinds & 2) && gl < G::A && ((legal >> gl) & 1u)) {
+                    const bool rev = (lf.flags & 2u) && !(lf.flags & 4u);
+                    const int rank = rev ? __popc(legal >> (gl + 1)) : __popc(legal & ((1u << gl) - 1u));
+                    if (rank < r.spec_width) spec_row<G>(d, g, gl, 1, s, gl);
+                }
             }
             parked = true;
             break;
@@ -859,9 +872,10 @@ template <class G, int BS, int GPW = 64 / G::LG>
 __global__ __launch_bounds__(BS) void k_tree_step(Dev d, int mode, u32* clear_count, Roll r) {
     tree_step_body<G, BS, GPW>(d, mode, clear_count, r);
 }
-// az_search of a handful of Connect4 games with speculative rows (one game per wave: nobody's walk waits for a neighbour's probes)
-__global__ __launch_bounds__(256) void k_tree_step_spec(Dev d, int mode, u32* clear_count, Roll r) {
-    tree_step_body<C4, 256, 1, true>(d, mode, clear_count, r);
+// the rolling step of Connect4 games with speculative rows (Speculation, above)
+template <int BS, int GPW>
+__global__ __launch_bounds__(BS) void k_tree_step_spec(Dev d, int mode, u32* clear_count, Roll r) {
+    tree_step_body<C4, BS, GPW, true>(d, mode, clear_count, r);
 }
 template <class G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tree_step_small(Dev d, int mode, u32* clear_count,
@@ -1203,9 +1217,13 @@ static int launch_tree_step(const Dev& d, int mode, u32* clear_count, hipStream_
     Roll r;
     memset(&r, 0, sizeof(r));
     if (roll) r = *roll;
-    if (r.on && r.search && d.spec_rows && d.cache && game_of(d) == AZ_GAME_C4) {
-        constexpr int gpb = 256 / 64;   // one game per wave
-        k_tree_step_spec<<<dim3((d.gn + gpb - 1) / gpb), dim3(256), 0, st>>>(d, mode, clear_count, r);
+    if (r.on && d.spec_rows && d.cache && game_of(d) == AZ_GAME_C4) {
+        // up to 256 games per launch: one game per wave (nobody's walk waits for a neighbour's probes; 512 slots in two cohorts: 1 191
+        // games/s against 947 with two games per wave); else the shapes of the plain step
+        if (d.gn <= 256) k_tree_step_spec<256, 1><<<dim3((d.gn + 3) / 4), dim3(256), 0, st>>>(d, mode, clear_count, r);
+        else if (d.gn <= 768) k_tree_step_spec<512, 2><<<dim3((d.gn + 15) / 16), dim3(512), 0, st>>>(d, mode, clear_count, r);
+        else if (d.gn <= 1536) k_tree_step_spec<512, 4><<<dim3((d.gn + 31) / 32), dim3(512), 0, st>>>(d, mode, clear_count, r);
+        else k_tree_step_spec<512, 8><<<dim3((d.gn + 63) / 64), dim3(512), 0, st>>>(d, mode, clear_count, r);
         AZ_HIP(hipGetLastError());
         return AZ_OK;
     }
@@ -1275,6 +1293,14 @@ int launch_roll_step(const Dev& d, int mode, u32* stale_count, const Play& p, in
     // az_search over a handful of games (the drop-in player's single game): nobody waits for anybody, a game walks until it finds a
     // leaf for the network
     if (search_cnt && d.gn <= 8 && !bud_env && !cap_env) r.budget = 0u, r.cap = 64;
+    // every speculative row is a row of K3 work: all of them while the launch stays within one workgroup per CU, fewer above
+    static const char* sw_env = getenv("AZ_SPEC_WIDTH");   // measurement hook
+    // (rolling self-play, games/s without / with: 32 slots 44 / 67 at width 7; 128: 168 / 272 at 7; 256: 346 / 382, 487, 518, 505 at
+    // 7, 3, 2, 1; 512 in two cohorts: 768 / 847, 937, 1 014, 1 191 at 7, 3, 2, 1; 1 024 in three: 1 723 / 1 748 at 1, 1 972 with the next
+    // sibling only; 2 048 in four: 3 433 / 2 135 at 1, 3 068 with the sibling only -- there K3 has no CU time to spare)
+    r.spec_width = sw_env ? atoi(sw_env) : (d.gn <= 64 ? 7 : (d.gn <= 128 ? 3 : (d.gn <= 192 ? 2 : 1)));
+    static const char* sk_env = getenv("AZ_SPEC_KINDS");   // measurement hook
+    r.spec_kinds = sk_env ? atoi(sk_env) : (d.gn <= 256 ? 3 : 1);
     r.S = S;
     r.first_n = first_n;
     r.move_mode = move_mode;

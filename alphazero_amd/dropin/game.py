@@ -82,7 +82,16 @@ class Game:
         try:
             eng.load_net(m.policy.export_flat())
             eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
+            # Games enter the trajectory buffer in the order in which they finish, and which of two games finishes first is a
+            # matter of timing (a tree step ends by the clock).  A caller that names a seed asks for a replay: its rows come
+            # in game-id order, whatever the timing was (one rank; under torch.distributed every rank's block is its own).
+            order = None
+            if rng_seed is not None and world == 1:
+                gid = eng.traj_fetch(clear=False)["game_id"]
+                order = torch.from_numpy(np.argsort(gid, kind="stable").astype(np.int64)).to(torch.device("cuda", dev_index))
             recs = TrajectoryGatherer(eng, torch.device("cuda", dev_index)).gather()
+            if order is not None and order.numel() == recs.shape[0]:
+                recs = recs.index_select(0, order)
         finally:
             eng.close()
         if hasattr(buffer, "store_many"):    # the drop-in ReplayBuffer keeps its row counter itself
@@ -111,6 +120,9 @@ class Game:
             eng.load_net(m.policy.export_flat())
             eng.selfplay_rolling(n_games, temp=float(temp), first_n_steps=int(first_n_steps))
             t = eng.traj_fetch(clear=True)
+            if rng_seed is not None:   # a replay: game-id order instead of completion order (which is a matter of timing)
+                o = np.argsort(t["game_id"], kind="stable")
+                t = {k: v[o] for k, v in t.items()}
         finally:
             eng.close()
         planes = env_planes_batch(game, t["states"])

@@ -175,7 +175,7 @@ int az_set_flip_stream(az_engine *e, const uint8_t *bits, int64_t n_per_game);
 /* ---- K2 (+K3): search ----------------------------------------------------------------------------------- */
 /* n_sims playouts for every slot: MCTS_AZ.get_action_visits' loop (MCTS.py:166-169), evaluator on device.
  * n_sims <= 0 uses cfg.n_playout.  Asynchronous on the engine stream (az_get_* calls synchronise), except for
- * AZ_EVAL_CNN engines of <= 512 slots with the evaluation cache (<= 32 without) -- first of all the drop-in player's
+ * AZ_EVAL_CNN engines of <= 1024 slots with the evaluation cache (<= 32 without) -- first of all the drop-in player's
  * single game -- where playouts that need no network evaluation (terminal node, position in the evaluation cache)
  * are finished in place, a leaf that waits for the network takes its unvisited siblings and its children along into
  * the same K3 launch (their answers go into the cache, where the next playouts find them), and the call returns when
